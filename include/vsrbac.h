@@ -1,0 +1,170 @@
+/*
+ * vsrbac.h — C ABI of libvsrbac: RBAC-filtered k-NN on AMD Instinct MI355X (gfx950).
+ *
+ * Drop-in boundary for ONE path of rjzhb/VectorSearch-RBAC: "distance(query, corpus rows) AND
+ * permission(user, row) -> top-k", which the reference runs inside PostgreSQL through pgvector
+ * (file:line below are relative to the reference tree):
+ *
+ *   pgvector/src/vector.c:549-563,568-594   VectorL2SquaredDistance, l2_distance, vector_l2_squared_distance
+ *   pgvector/src/vector.c:596-636           VectorInnerProduct, inner_product, vector_negative_inner_product
+ *   pgvector/src/vector.c:638-685           VectorCosineSimilarity, cosine_distance
+ *   pgvector/src/vector.c:714-739           VectorL1Distance, l1_distance
+ *   pgvector/src/hnswscan.c:179-316         hnswgettuple   (first call runs the whole search; later calls pop TIDs)
+ *   pgvector/src/ivfscan.c:339-389          ivfflatgettuple (same contract)
+ *   controller/baseline/pg_row_security/row_level_security.py:54-65   RLS policy = the per-row permission test
+ *   controller/baseline/prefilter/initialize_partitions.py:281-311    role tables  = pre-filter row sets
+ *   controller/dynamic_partition/search.py:54-58,347-364              comb_role -> partitions, merge + dedup
+ *
+ * A PostgreSQL extension shim keeps pgvector's SQL surface (type vector, operators
+ * <-> <#> <=> <+>, access methods hnsw / ivfflat, GUC names) and calls these entry points; the Python
+ * harness mirror (vectorsearch-rbac_amd/vsrbac) binds them with ctypes.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++ or torch types; every function returns a vsr_status (0 = ok)
+ *     unless stated; never throws, never exits.  vsr_last_error() gives the message of the last failure
+ *     on the calling thread (dimension mismatch keeps pgvector's text, vector.c:60-67).
+ *   - host pointers are borrowed for the duration of the call; the library owns all device memory.
+ *   - "_device" variants take device pointers and enqueue on the context's stream without synchronising.
+ *   - a context is bound to one GPU and one host thread at a time; open one context per process after
+ *     fork (PostgreSQL backends), never share across fork.
+ *   - there is no CPU fallback: without a usable gfx950 device vsr_open fails with VSR_ERR_NO_DEVICE.
+ */
+#ifndef VSRBAC_H
+#define VSRBAC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSR_ABI_VERSION 1
+
+typedef struct vsr_ctx vsr_ctx;
+typedef struct vsr_corpus vsr_corpus;
+typedef struct vsr_filter vsr_filter;
+
+typedef enum {
+    VSR_OK = 0,
+    VSR_ERR_INVALID = 1,        /* bad argument */
+    VSR_ERR_DIM_MISMATCH = 2,   /* "different vector dimensions %d and %d" (vector.c:60-67) */
+    VSR_ERR_NO_DEVICE = 3,      /* no gfx950 GPU / HIP runtime unusable */
+    VSR_ERR_HIP = 4,            /* a HIP call failed; see vsr_last_error() */
+    VSR_ERR_OOM = 5,
+    VSR_ERR_UNSUPPORTED = 6,    /* e.g. k > VSR_MAX_K */
+    VSR_ERR_NO_RBAC = 7         /* filter requested before vsr_rbac_load */
+} vsr_status;
+
+/* operator of pgvector/sql/vector.sql:174-192; the value returned is the operator's float8 result */
+typedef enum {
+    VSR_METRIC_L2 = 0,          /* <->  sqrt(sum (a-b)^2)            */
+    VSR_METRIC_IP = 1,          /* <#>  -sum a*b                     */
+    VSR_METRIC_COSINE = 2,      /* <=>  1 - clamp(cos(a,b)), NaN for a zero vector (sorted last) */
+    VSR_METRIC_L1 = 3           /* <+>  sum |a-b|                    */
+} vsr_metric;
+
+/* how a permission set is applied to the scan */
+typedef enum {
+    VSR_FILTER_RANGES = 0,      /* pre-filter: only the permitted row ranges are read (role / partition tables) */
+    VSR_FILTER_BITMAP = 1       /* post-filter: whole-corpus scan order, per-row permission bit tested in the
+                                   distance loop (row-level security); fully masked tiles are skipped */
+} vsr_filter_mode;
+
+#define VSR_MAX_K 2048
+
+/* ---- context -------------------------------------------------------------------------------- */
+int         vsr_abi_version(void);
+const char* vsr_last_error(void);
+const char* vsr_status_string(int status);
+
+int vsr_open(int device_ordinal, vsr_ctx** out);
+int vsr_close(vsr_ctx* ctx);
+/* use the caller's HIP stream (hipStream_t as void*, e.g. torch's current stream); NULL = own stream */
+int vsr_set_stream(vsr_ctx* ctx, void* hip_stream);
+int vsr_synchronize(vsr_ctx* ctx);
+int vsr_device_info(vsr_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
+
+/* ---- corpus: resident row-major fp32 rows + row identity -------------------------------------- */
+/* rows[n][dim]; block_ids[n] / doc_ids[n] identify a row as (document_id, block_id) like the reference's
+ * documentblocks table (controller/initialize_main_tables.py:54-61); either may be NULL (block_id = row
+ * index, document_id = 0).  Rows are re-ordered internally by (document_id, block_id); results report the
+ * caller's row index.  row_offset is added to internal rows in raw keys (multi-GPU shards; 0 otherwise). */
+int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int dim,
+                    const int64_t* block_ids, const int32_t* doc_ids, int64_t row_offset,
+                    vsr_corpus** out);
+int     vsr_corpus_free(vsr_corpus* corpus);
+int64_t vsr_corpus_rows(const vsr_corpus* corpus);
+int     vsr_corpus_dim(const vsr_corpus* corpus);
+
+/* ---- RBAC tables (UserRoles, PermissionAssignment of controller/initialize_main_tables.py:17-72) ---- */
+int vsr_rbac_load(vsr_corpus* corpus,
+                  const int32_t* ur_user, const int32_t* ur_role, int64_t n_user_roles,
+                  const int32_t* pa_role, const int32_t* pa_doc, int64_t n_permissions);
+
+/* ---- filters ----------------------------------------------------------------------------------- */
+/* rows visible to the user: EXISTS role in UserRoles(user): (role, document) in PermissionAssignment.
+ * Cached per role combination and mode; owned by the corpus (do not free). */
+int vsr_filter_for_user(vsr_corpus* corpus, int32_t user_id, int mode, vsr_filter** out);
+int vsr_filter_for_roles(vsr_corpus* corpus, const int32_t* role_ids, int n_roles, int mode, vsr_filter** out);
+/* byte-per-row mask in the caller's row order (uint8 allowed_mask[N] of global_hnsw_index.cpp:136-183,
+ * char filter map of acorn_benchmark/src/benchmark_utils.cpp:342-396).  Caller frees with vsr_filter_free. */
+int vsr_filter_from_bytemask(vsr_corpus* corpus, const uint8_t* allowed, int mode, vsr_filter** out);
+/* a dynamic partition = a set of documents (load_result_to_database.py:207-240); user_id >= 0 adds the
+ * per-row permission test of an "impure" partition (load_result_to_database.py:590-624), -1 = pure. */
+int vsr_filter_from_documents(vsr_corpus* corpus, const int32_t* doc_ids, int64_t n_docs, int32_t user_id,
+                              vsr_filter** out);
+int     vsr_filter_free(vsr_filter* filter);
+int64_t vsr_filter_allowed_rows(const vsr_filter* filter);   /* rows that pass the filter */
+int64_t vsr_filter_scanned_rows(const vsr_filter* filter);   /* rows whose distance work is priced (N for bitmap mode) */
+
+/* ---- search -------------------------------------------------------------------------------------- */
+/* nq queries of `dim` floats; filters[i] applies to query i (filters == NULL or filters[i] == NULL: no filter).
+ * Outputs are nq*k, row-major, ordered by (distance asc, NaN last, document_id asc, block_id asc); entries
+ * past out_counts[i] hold id -1 and +Inf.  out_rows (caller row index) and out_doc_ids may be NULL. */
+int vsr_search(vsr_corpus* corpus, const float* queries, int nq, int dim, int k, int metric,
+               const vsr_filter* const* filters,
+               int64_t* out_block_ids, int32_t* out_doc_ids, int64_t* out_rows,
+               float* out_dist, int32_t* out_counts);
+
+/* same, queries and outputs in device memory, enqueued on the context's stream, no synchronisation.
+ * out_keys (nq*k, may be NULL) receives the raw ordering keys (monotone fp32 distance << 32 | global row)
+ * that vsr_merge_topk_device consumes. */
+int vsr_search_device(vsr_corpus* corpus, const float* d_queries, int nq, int dim, int k, int metric,
+                      const vsr_filter* const* filters,
+                      int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows,
+                      float* d_out_dist, int32_t* d_out_counts, uint64_t* d_out_keys);
+
+/* merge n_parts per-shard results (layout [n_parts][nq][k], as all-gathered from vsr_search_device) into the
+ * global top-k: the client-side merge of search.py:347-364 done on the GPU. */
+int vsr_merge_topk_device(vsr_ctx* ctx, const uint64_t* d_keys, const int64_t* d_block_ids,
+                          const int32_t* d_doc_ids, const float* d_dist, int n_parts, int nq, int k,
+                          int64_t* d_out_block_ids, int32_t* d_out_doc_ids, float* d_out_dist,
+                          uint64_t* d_out_keys, int32_t* d_out_counts);
+
+/* operator value for n explicit pairs a[i] (dim floats) vs b[i] (or one shared b when b_broadcast != 0):
+ * what `SELECT a <-> b` evaluates per row (vector.c:568-578 etc.), batched.  Host pointers. */
+int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, const float* b, int64_t n_pairs,
+                       int dim_a, int dim_b, int b_broadcast, double* out);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t scan_launches;      /* K1 launches timed                                   */
+    double  scan_ms;            /* sum of their HIP-event durations                    */
+    int64_t scan_bytes;         /* algorithmic bytes: rows*dim*4 + bitmap bytes + k*12 */
+    int64_t scan_rows;          /* rows scanned (per shared pass)                      */
+    int64_t select_launches;
+    double  select_ms;
+    int64_t queries;
+} vsr_stats;
+
+int vsr_profiling(vsr_ctx* ctx, int enable);      /* HIP events around K1 / K5 on the launch stream */
+int vsr_stats_get(vsr_ctx* ctx, vsr_stats* out);  /* synchronises, accumulates pending events */
+int vsr_stats_reset(vsr_ctx* ctx);
+
+/* launch-shape knobs (measurement only): blocks per launch budget, min rows per workgroup, queries per pass */
+int vsr_tune(vsr_ctx* ctx, int block_budget, int min_rows_per_block, int max_queries_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSRBAC_H */

@@ -1,0 +1,357 @@
+"""GPU parity: libvsrbac (HIP, through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): returned row ids bit-exact at full recall, fp32 distances within 1e-4.
+Integer-valued (SIFT-like) data has exact fp32 sums in any order, so ids AND distances must be identical
+(tie groups included, tie rule = (distance, document_id, block_id)).  Real-valued data is summation-order
+ambiguous in the reference itself (-fassociative-math) and is checked with
+helpers.assert_valid_topk at 1e-4.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_valid_topk, sift_like
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vsrbac
+    c = vsrbac.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def known(golden_dir):
+    with open(os.path.join(golden_dir, "pgvector_known_answers.json")) as f:
+        return json.load(f)
+
+
+def _ids(n, rows_per_doc):
+    return (np.arange(n) + 1).astype(np.int64), (np.arange(n) // rows_per_doc + 1).astype(np.int32)
+
+
+def _expect_exact(oracle, res, qi, metric, x, q, k, doc, blk, mask=None):
+    idx, dist = oracle.filtered_topk(metric, x, q, k, doc, blk, mask)
+    m = res.counts[qi]
+    assert m == idx.size, (m, idx.size)
+    np.testing.assert_array_equal(res.rows[qi, :m], idx)
+    np.testing.assert_array_equal(res.block_ids[qi, :m], blk[idx])
+    np.testing.assert_array_equal(res.doc_ids[qi, :m], doc[idx])
+    np.testing.assert_array_equal(res.dist[qi, :m], dist.astype(np.float32))
+    assert (res.block_ids[qi, m:] == -1).all() and np.isinf(res.dist[qi, m:]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# pgvector known answers through the GPU path
+# ---------------------------------------------------------------------------------------------
+def test_pair_distance_known_answers(ctx, known):
+    import vsrbac
+    metric = {"l2_distance": "l2", "negative_inner_product": "ip", "cosine_distance": "cosine", "l1_distance": "l1"}
+    for fn, a, b, want in known["distances"]:
+        if fn == "inner_product":          # SQL function inner_product = -(<#>)
+            fn, want = "negative_inner_product", (-want if not isinstance(want, str) else want)
+            if want == "Infinity":
+                want = "-Infinity"
+        if isinstance(want, str) and want.startswith("ERROR:"):
+            with pytest.raises(vsrbac.VsrError) as e:
+                ctx.pair_distances(metric[fn], [a], b)
+            assert "ERROR:  " + str(e.value) == want
+            continue
+        got = ctx.pair_distances(metric[fn], [a], b)[0]
+        if want == "Infinity":
+            assert math.isinf(got) and got > 0
+        elif want == "-Infinity":
+            assert math.isinf(got) and got < 0
+        elif want == "NaN":
+            assert math.isnan(got)
+        else:
+            assert got == want
+
+
+def test_ordering_known_answers(ctx, known):
+    o = known["ordering"]
+    rows = np.asarray(o["rows"], dtype=np.float32)
+    corpus = ctx.load_corpus(rows)
+    for metric in ("l2", "ip", "l1"):
+        res = corpus.search(o["query"], 4, metric)
+        assert rows[res.rows[0]].tolist() == o[metric]
+    res = corpus.search(o["query"], 4, "cosine")
+    assert rows[res.rows[0, :3]].tolist() == o["cosine_index"]
+    assert math.isnan(res.dist[0, 3]) and res.rows[0, 3] == 0       # zero vector: NaN, sorted last
+    corpus.free()
+
+
+def test_dimension_mismatch_message(ctx):
+    import vsrbac
+    corpus = ctx.load_corpus(np.zeros((4, 2), dtype=np.float32))
+    with pytest.raises(vsrbac.VsrError) as e:
+        corpus.search([[1.0]], 1)
+    assert str(e.value) == "different vector dimensions 2 and 1"     # vector.c:60-67
+    assert e.value.status == 2
+    corpus.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# config 1 shape: 10k x 128, k = 10, no filter; plus k = 100
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 10, 100])
+def test_sift10k_unfiltered_bit_exact(ctx, oracle, k):
+    rng = np.random.default_rng(1)
+    n = 10_000
+    x = sift_like(rng, n)
+    blk, doc = _ids(n, 100)
+    corpus = ctx.load_corpus(x, blk, doc)
+    qrows = rng.integers(0, n, 8)
+    res = corpus.search(x[qrows], k, "l2")
+    for i, qr in enumerate(qrows):
+        _expect_exact(oracle, res, i, "l2", x, x[qr], k, doc, blk)
+        assert res.rows[i, 0] == qr or res.dist[i, 0] == 0
+    corpus.free()
+
+
+def test_ties_follow_doc_block_order(ctx, oracle):
+    """Many exact ties (duplicated rows, shuffled identity): order must be (dist, document_id, block_id)."""
+    rng = np.random.default_rng(2)
+    base = sift_like(rng, 50)
+    x = np.repeat(base, 40, axis=0)                      # 2000 rows, each vector 40 times
+    perm = rng.permutation(x.shape[0])
+    x = x[perm]
+    blk = rng.permutation(x.shape[0]).astype(np.int64) + 1        # identities unrelated to row order
+    doc = rng.integers(1, 30, x.shape[0]).astype(np.int32)
+    corpus = ctx.load_corpus(x, blk, doc)
+    res = corpus.search(base[:5], 100, "l2")
+    for i in range(5):
+        _expect_exact(oracle, res, i, "l2", x, base[i], 100, doc, blk)
+    corpus.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# RBAC: fixtures produced by the reference's generators (tests/golden/make_rbac_fixture.py)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,rows_per_doc", [("rbac_tree_small.json", 20), ("rbac_random_small.json", 7)])
+def test_rbac_prefilter_and_postfilter(ctx, oracle, golden_dir, name, rows_per_doc):
+    import vsrbac
+    with open(os.path.join(golden_dir, name)) as f:
+        fx = json.load(f)
+    rng = np.random.default_rng(3)
+    ndocs = fx["params"]["num_docs"]
+    n = ndocs * rows_per_doc
+    x = sift_like(rng, n)
+    blk, doc = _ids(n, rows_per_doc)
+    corpus = ctx.load_corpus(x, blk, doc)
+    corpus.load_rbac(fx["user_roles"], fx["permissions"])
+    users = list(range(1, fx["num_users"] + 1))
+    qrows = rng.integers(0, n, len(users))
+    masks = [oracle.user_row_mask(u, fx["user_roles"], fx["permissions"], doc) for u in users]
+    for mode in (vsrbac.RANGES, vsrbac.BITMAP):
+        filters = [corpus.filter_for_user(u, mode) for u in users]
+        for u, f, m in zip(users, filters, masks):
+            assert f.allowed_rows == int(m.sum()) == rows_per_doc * len(fx["visible_docs"][str(u)])
+        res = corpus.search(x[qrows], 100, "l2", filters)          # one batch, mixed users (shared passes)
+        for i in range(len(users)):
+            _expect_exact(oracle, res, i, "l2", x, x[qrows[i]], 100, doc, blk, masks[i])
+        one = corpus.search(x[qrows[:3]], 10, "l2", filters[:3])   # and small k, few queries
+        for i in range(3):
+            _expect_exact(oracle, one, i, "l2", x, x[qrows[i]], 10, doc, blk, masks[i])
+    # a user the tables do not know sees nothing
+    res = corpus.search(x[:1], 10, "l2", [corpus.filter_for_user(10_000_000, vsrbac.RANGES)])
+    assert res.counts[0] == 0 and (res.block_ids[0] == -1).all()
+    corpus.free()
+
+
+def test_bytemask_and_document_filters(ctx, oracle, golden_dir):
+    import vsrbac
+    with open(os.path.join(golden_dir, "rbac_tree_small.json")) as f:
+        fx = json.load(f)
+    rng = np.random.default_rng(4)
+    rows_per_doc = 10
+    n = fx["params"]["num_docs"] * rows_per_doc
+    x = sift_like(rng, n)
+    blk, doc = _ids(n, rows_per_doc)
+    corpus = ctx.load_corpus(x, blk, doc)
+    corpus.load_rbac(fx["user_roles"], fx["permissions"])
+    q = x[rng.integers(0, n, 4)]
+    # arbitrary predicate: byte-per-row mask (ACORN / logical-partition convention)
+    mask = (rng.random(n) < 0.05).astype(np.uint8)
+    for mode in (vsrbac.RANGES, vsrbac.BITMAP):
+        f = corpus.filter_from_bytemask(mask, mode)
+        assert f.allowed_rows == int(mask.sum())
+        res = corpus.search(q, 50, "l2", f)
+        for i in range(4):
+            _expect_exact(oracle, res, i, "l2", x, q[i], 50, doc, blk, mask)
+        f.free()
+    # dynamic partition = a document set; pure (no per-row test) and impure (with the user's permission)
+    part_docs = rng.choice(np.arange(1, fx["params"]["num_docs"] + 1), 80, replace=False)
+    in_part = np.isin(doc, part_docs).astype(np.uint8)
+    f = corpus.filter_from_documents(part_docs)
+    res = corpus.search(q, 30, "l2", f)
+    for i in range(4):
+        _expect_exact(oracle, res, i, "l2", x, q[i], 30, doc, blk, in_part)
+    user = 7
+    um = oracle.user_row_mask(user, fx["user_roles"], fx["permissions"], doc)
+    f2 = corpus.filter_from_documents(part_docs, user_id=user)
+    res = corpus.search(q, 30, "l2", f2)
+    for i in range(4):
+        _expect_exact(oracle, res, i, "l2", x, q[i], 30, doc, blk, in_part & um)
+    corpus.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# every kernel shape (dimension classes), every metric, real-valued data -> tolerance
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [1, 3, 9, 16, 17, 50, 64, 100, 128, 129, 200, 256, 300, 512, 768, 960, 1024, 1536, 2000, 4100])
+def test_dimension_classes_l2(ctx, dim):
+    rng = np.random.default_rng(dim)
+    n, k = 1500, 20
+    x = rng.normal(size=(n, dim)).astype(np.float32)
+    q = rng.normal(size=(3, dim)).astype(np.float32)
+    corpus = ctx.load_corpus(x)
+    res = corpus.search(q, k, "l2")
+    for i in range(3):
+        ref = np.sqrt(((x.astype(np.float64) - q[i].astype(np.float64)) ** 2).sum(1))
+        assert_valid_topk(res.rows[i, :res.counts[i]], res.dist[i, :res.counts[i]], ref, k, TOL)
+    corpus.free()
+
+
+def _ref_all(metric, x, q):
+    x64, q64 = x.astype(np.float64), q.astype(np.float64)
+    if metric == "l2":
+        return np.sqrt(((x64 - q64) ** 2).sum(1))
+    if metric == "ip":
+        return -(x64 @ q64)
+    if metric == "l1":
+        return np.abs(x64 - q64).sum(1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sim = (x64 @ q64) / np.sqrt((x64 ** 2).sum(1) * (q64 ** 2).sum())
+    return 1.0 - np.clip(sim, -1, 1)
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip", "cosine", "l1"])
+@pytest.mark.parametrize("dim", [128, 768])
+def test_metrics_real_valued(ctx, oracle, metric, dim):
+    rng = np.random.default_rng(11)
+    n, k = 4000, 100
+    x = rng.normal(size=(n, dim)).astype(np.float32)
+    if metric == "cosine":
+        x /= np.linalg.norm(x, axis=1, keepdims=True)             # config 3: L2-normalised rows
+        x[5] = 0                                                  # one zero vector -> NaN distance, sorted last
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    q = x[rng.integers(10, n, 6)] + 0.01 * rng.normal(size=(6, dim)).astype(np.float32)
+    corpus = ctx.load_corpus(x)
+    f = corpus.filter_from_bytemask(mask)
+    res = corpus.search(q, k, metric, f)
+    for i in range(6):
+        ref = _ref_all(metric, x, q[i])
+        m = res.counts[i]
+        assert m == k
+        assert_valid_topk(res.rows[i, :m], res.dist[i, :m], ref, k, TOL, candidates=np.flatnonzero(mask))
+        # and the oracle's own values agree within the same tolerance
+        oidx, odist = oracle.filtered_topk(metric, x, q[i], k, mask=mask)
+        np.testing.assert_allclose(res.dist[i, :m], odist, rtol=TOL, atol=TOL)
+    corpus.free()
+
+
+def test_cosine_nan_rows_sort_last(ctx, oracle):
+    x = np.asarray([[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 0], [1, 1, 0, 0]], dtype=np.float32)
+    corpus = ctx.load_corpus(x)
+    res = corpus.search([[1, 0, 0, 0]], 5, "cosine")
+    idx, dist = oracle.filtered_topk("cosine", x, [1, 0, 0, 0], 5)
+    np.testing.assert_array_equal(res.rows[0], idx)
+    assert np.isnan(res.dist[0, 3:]).all() and np.isnan(dist[3:]).all()
+    np.testing.assert_allclose(res.dist[0, :3], dist[:3], atol=1e-6)
+    corpus.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# k range, empty / ragged inputs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 2, 100, 128, 129, 500, 1024, 2048])
+def test_k_range(ctx, oracle, k):
+    rng = np.random.default_rng(5)
+    n = 9000
+    x = sift_like(rng, n)
+    blk, doc = _ids(n, 100)
+    corpus = ctx.load_corpus(x, blk, doc)
+    q = x[rng.integers(0, n, 2)]
+    res = corpus.search(q, k, "l2")
+    for i in range(2):
+        _expect_exact(oracle, res, i, "l2", x, q[i], k, doc, blk)
+    corpus.free()
+
+
+def test_k_larger_than_rows_and_empty(ctx, oracle):
+    import vsrbac
+    rng = np.random.default_rng(6)
+    x = sift_like(rng, 37)
+    blk, doc = _ids(37, 5)
+    corpus = ctx.load_corpus(x, blk, doc)
+    res = corpus.search(x[:2], 100, "l2")
+    for i in range(2):
+        _expect_exact(oracle, res, i, "l2", x, x[i], 100, doc, blk)
+    none = corpus.filter_from_bytemask(np.zeros(37, np.uint8), vsrbac.BITMAP)
+    res = corpus.search(x[:2], 10, "l2", none)
+    assert (res.counts == 0).all() and (res.block_ids == -1).all() and np.isinf(res.dist).all()
+    with pytest.raises(vsrbac.VsrError):
+        corpus.search(x[:1], 0, "l2")
+    with pytest.raises(vsrbac.VsrError) as e:
+        corpus.search(x[:1], 5000, "l2")
+    assert e.value.status == 6
+    corpus.free()
+    empty = ctx.load_corpus(np.zeros((0, 8), dtype=np.float32))
+    res = empty.search(np.zeros((1, 8), np.float32), 5, "l2")
+    assert res.counts[0] == 0
+    empty.free()
+
+
+def test_unsorted_identities_are_reordered(ctx, oracle):
+    """Rows arrive in arbitrary (document, block) order; results report the caller's row index."""
+    rng = np.random.default_rng(8)
+    n = 3000
+    x = sift_like(rng, n, 32)
+    doc = rng.integers(1, 40, n).astype(np.int32)
+    blk = rng.permutation(n).astype(np.int64)
+    corpus = ctx.load_corpus(x, blk, doc)
+    res = corpus.search(x[:4], 64, "l2")
+    for i in range(4):
+        _expect_exact(oracle, res, i, "l2", x, x[i], 64, doc, blk)
+    corpus.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 2 at full size: SIFT1M-like, k = 100, role-partition prefilter (one GPU)
+# ---------------------------------------------------------------------------------------------
+def test_config2_sift1m_role_prefilter(ctx, oracle):
+    import vsrbac
+    from vsrbac.datasets import sift_like_corpus, tree_rbac
+    n = 1_000_000
+    x, blk, doc = sift_like_corpus(n, 128, seed=20251121)
+    rbac = tree_rbac(num_users=1000, num_roles=100, num_docs=n // 100, seed=20251121)
+    corpus = ctx.load_corpus(x, blk, doc)
+    corpus.load_rbac(rbac.user_roles, rbac.permissions)
+    rng = np.random.default_rng(9)
+    users = rng.integers(1, 1001, 64)
+    qrows = rng.integers(0, n, 64)
+    for mode in (vsrbac.RANGES, vsrbac.BITMAP):
+        filters = [corpus.filter_for_user(int(u), mode) for u in users]
+        res = corpus.search(x[qrows], 100, "l2", filters)
+        for i in range(0, 64, 8):                                    # oracle on a sample: ~0.1 s per query
+            mask = oracle.user_row_mask(int(users[i]), rbac.user_roles, rbac.permissions, doc)
+            _expect_exact(oracle, res, i, "l2", x, x[qrows[i]], 100, doc, blk, mask)
+        # size-independent properties on every query: sorted, permitted, self-match first, full count
+        for i in range(64):
+            assert res.counts[i] == 100
+            d = res.dist[i]
+            assert (np.diff(d) >= 0).all()
+            vis = rbac.visible_docs(int(users[i]))
+            assert np.isin(res.doc_ids[i], vis).all()
+            recomputed = np.sqrt(((x[res.rows[i]].astype(np.float64) - x[qrows[i]].astype(np.float64)) ** 2).sum(1))
+            np.testing.assert_array_equal(d, recomputed.astype(np.float32))
+    corpus.free()

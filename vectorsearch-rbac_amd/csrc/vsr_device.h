@@ -1,0 +1,100 @@
+// vsr_device.h — shared host/device definitions of the gfx950 kernels (internal, not the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsr {
+
+constexpr uint64_t KEY_EMPTY = ~0ull;     // sorts after every real key (NaN keys included)
+constexpr int      SCAN_THREADS = 512;    // 8 waves per workgroup
+constexpr int      SCAN_WAVES = SCAN_THREADS / 64;
+constexpr int      SELECT_THREADS = 1024;
+constexpr int      APPEND_SLACK = 512;    // max keys appended between two overflow checks
+constexpr int      MAX_K = 2048;
+
+enum Metric : int { M_L2 = 0, M_IP = 1, M_COSINE = 2, M_L1 = 3 };
+
+// One unit of scan work: a (filter, <=QB queries) pair, spread over n_blocks workgroups.
+struct ScanGroup {
+    const uint2*    tiles;         // (row_start, n_rows<=RW) list; nullptr => implicit tiles over [0, n_rows)
+    const uint64_t* bitmap;        // per-row permission bits over internal row order; nullptr => none
+    uint32_t        n_tiles;
+    uint32_t        q_begin;       // first query slot (queries of a group are contiguous)
+    uint32_t        q_count;       // 1..QB
+    uint32_t        block_begin;   // first workgroup of this group in the launch
+    uint32_t        n_blocks;
+    uint32_t        partial_begin; // partial list index = partial_begin + qi * n_blocks + local_block
+};
+
+struct ScanParams {
+    const float4*    rows;         // [n_rows][stride4] row-major, zero padded
+    const float*     norm2;        // [n_rows] sum x^2 (cosine)
+    uint32_t         n_rows;
+    uint32_t         stride4;      // float4 per row
+    const float*     queries;      // [n_slots][stride4*4], zero padded
+    const float*     q_norm2;      // [n_slots]
+    const ScanGroup* groups;
+    uint32_t         n_groups;
+    uint64_t*        partial;      // [n_partial][kp] keys, KEY_EMPTY padded
+    uint32_t         kp;           // partial list length (>= k)
+    uint32_t         k;
+    uint32_t         cap;          // LDS candidate capacity per query (power of two)
+};
+
+// Per query: which partial lists to merge and where to put the result.
+struct SelectQuery {
+    uint32_t partial_begin;
+    uint32_t n_lists;              // lists are partial_begin + j, j < n_lists
+    uint32_t out_slot;             // output row in the result arrays (caller's query index)
+    uint32_t pad;
+};
+
+struct SelectParams {
+    const uint64_t*    partial;
+    const SelectQuery* queries;
+    uint32_t           kp;
+    uint32_t           k;
+    uint32_t           cap;
+    int                metric;
+    uint32_t           row_offset;     // added to internal rows in out_keys (shard offset)
+    // id maps of the corpus (internal row order)
+    const int64_t*     block_ids;
+    const int32_t*     doc_ids;
+    const int64_t*     orig_rows;
+    // outputs, [n_queries][k]
+    int64_t*           out_block;
+    int32_t*           out_doc;
+    int64_t*           out_row;
+    float*             out_dist;
+    uint64_t*          out_keys;       // optional raw keys (multi-GPU merge)
+    int32_t*           out_count;
+};
+
+struct KernelShape {
+    int lpr;     // lanes per row
+    int c;       // float4 chunks per lane per row (0 = runtime loop)
+    int r;       // row slots per lane group per iteration
+    int rw;      // rows per wave iteration = r * (64 / lpr)
+};
+
+// host-side launchers (vsr_kernels.hip)
+KernelShape scan_shape_for_dim(int dim);
+int  scan_max_qb(int dim, int k);
+hipError_t launch_scan(const ScanParams& p, int metric, int dim, int qb, uint32_t n_blocks, hipStream_t s);
+hipError_t launch_select(const SelectParams& p, uint32_t n_queries, hipStream_t s);
+hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);
+hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,
+                               uint32_t words, const uint64_t* user_mask, uint64_t* bitmap, hipStream_t s);
+hipError_t launch_pack_bytemask(const uint8_t* mask_by_orig_row, const int64_t* orig_rows, uint32_t n_rows,
+                                uint64_t* bitmap, hipStream_t s);
+hipError_t launch_pair_distances(const float* a, const float* b, int64_t n_pairs, int dim, int b_broadcast,
+                                 int metric, double* out, hipStream_t s);
+hipError_t launch_merge_lists(const uint64_t* keys, const int64_t* blocks, const int32_t* docs, const float* dist,
+                              uint32_t n_parts, uint32_t n_queries, uint32_t k, int64_t* out_block,
+                              int32_t* out_doc, float* out_dist, uint64_t* out_keys, int32_t* out_count,
+                              hipStream_t s);
+hipError_t launch_gather_queries(const float* src, const uint32_t* slot_query, uint32_t nq, uint32_t dim,
+                                 uint32_t qfloats, float* dst, hipStream_t s);
+uint32_t cap_for_k(int k);
+
+}  // namespace vsr

@@ -1,0 +1,368 @@
+// vsr_kernels.hip — K5 (top-k select / merge) and the small support kernels of the filtered k-NN path.
+#include "vsr_device.h"
+#include "vsr_topk.h"
+
+namespace vsr {
+
+// per-metric scan launchers live in their own translation units (vsr_scan_*.hip)
+hipError_t launch_scan_l2(const ScanParams&, int, int, uint32_t, hipStream_t);
+hipError_t launch_scan_ip(const ScanParams&, int, int, uint32_t, hipStream_t);
+hipError_t launch_scan_cosine(const ScanParams&, int, int, uint32_t, hipStream_t);
+hipError_t launch_scan_l1(const ScanParams&, int, int, uint32_t, hipStream_t);
+
+KernelShape scan_shape_for_dim(int dim)
+{
+    const int d4 = (dim + 3) / 4;
+    if (d4 <= 1)   return {1, 1, 1, 64};
+    if (d4 <= 4)   return {4, 1, 4, 64};
+    if (d4 <= 16)  return {16, 1, 8, 32};
+    if (d4 <= 32)  return {32, 1, 8, 16};
+    if (d4 <= 64)  return {64, 1, 8, 8};
+    if (d4 <= 128) return {64, 2, 4, 4};
+    if (d4 <= 192) return {64, 3, 4, 4};
+    if (d4 <= 256) return {64, 4, 2, 2};
+    return {64, 0, 2, 2};
+}
+
+uint32_t cap_for_k(int k)
+{
+    // room for k kept keys + APPEND_SLACK new ones, with a trigger level >= 2k so compactions amortise
+    uint32_t cap = 1024;
+    while (cap < (uint32_t) (2 * k + APPEND_SLACK)) cap <<= 1;
+    return cap;
+}
+
+int scan_max_qb(int dim, int k)
+{
+    const KernelShape sh = scan_shape_for_dim(dim);
+    if (sh.c == 0) return 1;
+    return (size_t) 4 * cap_for_k(k) * sizeof(uint64_t) <= 64 * 1024 ? 4 : 1;
+}
+
+hipError_t launch_scan(const ScanParams& p, int metric, int dim, int qb, uint32_t n_blocks, hipStream_t s)
+{
+    switch (metric) {
+    case M_L2:     return launch_scan_l2(p, dim, qb, n_blocks, s);
+    case M_IP:     return launch_scan_ip(p, dim, qb, n_blocks, s);
+    case M_COSINE: return launch_scan_cosine(p, dim, qb, n_blocks, s);
+    case M_L1:     return launch_scan_l1(p, dim, qb, n_blocks, s);
+    default:       return hipErrorInvalidValue;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// K5: per query, the k smallest keys among its partial lists -> sorted output rows.
+// Replaces the executor's top-N sort / the client-side merge of
+// controller/dynamic_partition/search.py:347-364 (no dedup needed: a row is scanned once).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float output_distance(int metric, float v)
+{
+    // L2 ranks by the fp32 sum; the operator value is sqrt((double) sum), vector.c:577
+    return metric == M_L2 ? (float) sqrt((double) v) : v;
+}
+
+__global__ __launch_bounds__(SELECT_THREADS) void select_kernel(const SelectParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const SelectQuery sq = p.queries[blockIdx.x];
+    const uint32_t cap = p.cap, k = p.k;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(keys + cap);
+    if (tid == 0) {
+        ctrl->tau = KEY_EMPTY;
+        ctrl->count = 0;
+    }
+    __syncthreads();
+
+    const uint64_t* src = p.partial + (size_t) sq.partial_begin * p.kp;
+    const uint64_t total = (uint64_t) sq.n_lists * p.kp;
+    const uint32_t trigger = cap - SELECT_THREADS;
+    for (uint64_t base = 0; base < total; base += SELECT_THREADS) {
+        const uint64_t i = base + tid;
+        const uint64_t key = i < total ? src[i] : KEY_EMPTY;
+        const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl->tau);
+        topk_append(keys, ctrl, key < tau, key);            // KEY_EMPTY never passes (tau <= KEY_EMPTY)
+        const bool need = *reinterpret_cast<volatile uint32_t*>(&ctrl->count) > trigger;
+        if (base + SELECT_THREADS < total && __syncthreads_or(need))
+            topk_compact<SELECT_THREADS>(keys, ctrl, k, tid, false);
+    }
+    __syncthreads();
+    topk_compact<SELECT_THREADS>(keys, ctrl, k, tid, true);
+
+    const uint32_t m = ctrl->count < k ? ctrl->count : k;
+    const size_t out = (size_t) sq.out_slot * k;
+    for (uint32_t i = tid; i < k; i += SELECT_THREADS) {
+        if (i < m) {
+            const uint64_t key = keys[i];
+            const uint32_t row = (uint32_t) key;
+            const float v = mono_to_float((uint32_t) (key >> 32));
+            p.out_block[out + i] = p.block_ids[row];
+            p.out_doc[out + i] = p.doc_ids[row];
+            if (p.out_row) p.out_row[out + i] = p.orig_rows[row];
+            p.out_dist[out + i] = output_distance(p.metric, v);
+            if (p.out_keys) p.out_keys[out + i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t) (row + p.row_offset);
+        } else {
+            p.out_block[out + i] = -1;
+            p.out_doc[out + i] = -1;
+            if (p.out_row) p.out_row[out + i] = -1;
+            p.out_dist[out + i] = __builtin_inff();
+            if (p.out_keys) p.out_keys[out + i] = KEY_EMPTY;
+        }
+    }
+    if (tid == 0) p.out_count[sq.out_slot] = (int32_t) m;
+}
+
+hipError_t launch_select(const SelectParams& p, uint32_t n_queries, hipStream_t s)
+{
+    const size_t lds = (size_t) p.cap * sizeof(uint64_t) + sizeof(TopKCtrl);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(select_kernel, dim3(n_queries), dim3(SELECT_THREADS), lds, s, p);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Multi-GPU merge: n_parts per-shard sorted result lists per query -> global top-k (K5 on the
+// all-gathered candidates).  keys carry (monotone distance, global row), so the order across shards
+// is the same total order as on one GPU.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_lists_kernel(const uint64_t* keys, const int64_t* blocks,
+                                                          const int32_t* docs, const float* dist,
+                                                          uint32_t n_parts, uint32_t n_queries, uint32_t k,
+                                                          uint32_t np2, int64_t* out_block, int32_t* out_doc,
+                                                          float* out_dist, uint64_t* out_keys, int32_t* out_count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* skey = reinterpret_cast<uint64_t*>(smem);          // [np2]
+    uint32_t* spos = reinterpret_cast<uint32_t*>(skey + np2);    // [np2]
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t total = n_parts * k;
+    for (uint32_t i = tid; i < np2; i += 256) {
+        uint64_t key = KEY_EMPTY;
+        uint32_t pos = 0;
+        if (i < total) {
+            const uint32_t part = i / k, j = i % k;
+            pos = (part * n_queries + q) * k + j;
+            key = keys[pos];
+        }
+        skey[i] = key;
+        spos[i] = pos;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (np2 >> 1); t += 256) {
+                const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = skey[i], b = skey[j];
+                if ((a > b) == up) {
+                    skey[i] = b; skey[j] = a;
+                    const uint32_t pa = spos[i]; spos[i] = spos[j]; spos[j] = pa;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    uint32_t m = 0;
+    for (uint32_t i = tid; i < k; i += 256) {
+        const size_t o = (size_t) q * k + i;
+        const uint64_t key = i < np2 ? skey[i] : KEY_EMPTY;
+        if (key != KEY_EMPTY) {
+            const uint32_t pos = spos[i];
+            out_block[o] = blocks[pos];
+            out_doc[o] = docs[pos];
+            out_dist[o] = dist[pos];
+            if (out_keys) out_keys[o] = key;
+        } else {
+            out_block[o] = -1;
+            out_doc[o] = -1;
+            out_dist[o] = __builtin_inff();
+            if (out_keys) out_keys[o] = KEY_EMPTY;
+        }
+    }
+    // count = number of real keys among the first k (keys are sorted, EMPTY last)
+    if (tid == 0) {
+        const uint32_t lim = k < np2 ? k : np2;
+        uint32_t lo = 0, hi = lim;                   // first EMPTY position
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (skey[mid] != KEY_EMPTY) lo = mid + 1; else hi = mid;
+        }
+        m = lo;
+        out_count[q] = (int32_t) m;
+    }
+}
+
+hipError_t launch_merge_lists(const uint64_t* keys, const int64_t* blocks, const int32_t* docs, const float* dist,
+                              uint32_t n_parts, uint32_t n_queries, uint32_t k, int64_t* out_block,
+                              int32_t* out_doc, float* out_dist, uint64_t* out_keys, int32_t* out_count,
+                              hipStream_t s)
+{
+    uint32_t np2 = 2;
+    while (np2 < n_parts * k) np2 <<= 1;
+    const size_t lds = (size_t) np2 * (sizeof(uint64_t) + sizeof(uint32_t));
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_lists_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(merge_lists_kernel, dim3(n_queries), dim3(256), lds, s, keys, blocks, docs, dist, n_parts,
+                       n_queries, k, np2, out_block, out_doc, out_dist, out_keys, out_count);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Row norms (sum x^2 in fp32, the normb accumulator of vector.c:638-655), one wave per row.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_norms_kernel(const float4* rows, uint32_t n_rows, uint32_t stride4,
+                                                        float* norm2)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * 256) >> 6;
+    for (uint32_t r = wave; r < n_rows; r += n_waves) {
+        float s = 0.0f;
+        for (uint32_t c = lane; c < stride4; c += 64) {
+            const float4 x = rows[(size_t) r * stride4 + c];
+            s = fmaf(x.x, x.x, s); s = fmaf(x.y, x.y, s); s = fmaf(x.z, x.z, s); s = fmaf(x.w, x.w, s);
+        }
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) norm2[r] = s;
+    }
+}
+
+hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    uint32_t blocks = (n_rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, s, rows, n_rows, stride4, norm2);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Permission bitmaps.  allowed(user,row) <=> docmask[doc(row)] & usermask != 0
+// (row_level_security.py:54-65 with PermissionAssignment folded into per-document role bitsets).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_bitmap_kernel(const uint32_t* row_doc_idx, uint32_t n_rows,
+                                                           const uint64_t* doc_mask, uint32_t words,
+                                                           const uint64_t* user_mask, uint64_t* bitmap)
+{
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    bool allowed = false;
+    if (row < n_rows) {
+        const uint64_t* dm = doc_mask + (size_t) row_doc_idx[row] * words;
+        for (uint32_t w = 0; w < words; ++w) allowed |= (dm[w] & user_mask[w]) != 0;
+    }
+    const uint64_t bits = __ballot(allowed);
+    if ((threadIdx.x & 63) == 0 && row < n_rows) bitmap[row >> 6] = bits;
+}
+
+hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,
+                               uint32_t words, const uint64_t* user_mask, uint64_t* bitmap, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(build_bitmap_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, row_doc_idx, n_rows,
+                       doc_mask, words, user_mask, bitmap);
+    return hipGetLastError();
+}
+
+// byte-per-row masks in the caller's row order (acorn_benchmark/src/benchmark_utils.cpp:366-391,
+// test_postfilter.cpp:169-195) -> bit-per-row in internal order
+__global__ __launch_bounds__(256) void pack_bytemask_kernel(const uint8_t* mask_by_orig, const int64_t* orig_rows,
+                                                            uint32_t n_rows, uint64_t* bitmap)
+{
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    const bool allowed = row < n_rows && mask_by_orig[orig_rows[row]] != 0;
+    const uint64_t bits = __ballot(allowed);
+    if ((threadIdx.x & 63) == 0 && row < n_rows) bitmap[row >> 6] = bits;
+}
+
+hipError_t launch_pack_bytemask(const uint8_t* mask_by_orig, const int64_t* orig_rows, uint32_t n_rows,
+                                uint64_t* bitmap, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_bytemask_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, mask_by_orig, orig_rows,
+                       n_rows, bitmap);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Batched operator values for explicit vector pairs: the fmgr functions l2_distance,
+// vector_negative_inner_product, cosine_distance, l1_distance (vector.c:568-578, 626-636, 660-685,
+// 729-739) for n pairs at once.  One wave per pair, fp32 accumulate, float8 post-processing.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_distance_kernel(const float* a, const float* b, int64_t n_pairs, int dim,
+                                                            int b_broadcast, int metric, double* out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t) blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t) gridDim.x * 256) >> 6;
+    for (int64_t i = wave; i < n_pairs; i += n_waves) {
+        const float* x = a + i * dim;
+        const float* y = b_broadcast ? b : b + i * dim;
+        float s = 0.0f, na = 0.0f, nb = 0.0f;
+        for (int j = lane; j < dim; j += 64) {
+            const float u = x[j], v = y[j];
+            if (metric == M_L2) { const float d = u - v; s = fmaf(d, d, s); }
+            else if (metric == M_L1) s += fabsf(u - v);
+            else {
+                s = fmaf(u, v, s);
+                if (metric == M_COSINE) { na = fmaf(u, u, na); nb = fmaf(v, v, nb); }
+            }
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            s += __shfl_xor(s, m);
+            na += __shfl_xor(na, m);
+            nb += __shfl_xor(nb, m);
+        }
+        if (lane == 0) {
+            double r;
+            if (metric == M_L2) r = sqrt((double) s);
+            else if (metric == M_IP) r = (double) -s;
+            else if (metric == M_L1) r = (double) s;
+            else {
+                double sim = (double) s / sqrt((double) na * (double) nb);
+                if (sim > 1.0) sim = 1.0; else if (sim < -1.0) sim = -1.0;
+                r = 1.0 - sim;
+            }
+            out[i] = r;
+        }
+    }
+}
+
+hipError_t launch_pair_distances(const float* a, const float* b, int64_t n_pairs, int dim, int b_broadcast,
+                                 int metric, double* out, hipStream_t s)
+{
+    if (n_pairs == 0) return hipSuccess;
+    int64_t blocks = (n_pairs + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pair_distance_kernel, dim3((uint32_t) blocks), dim3(256), 0, s, a, b, n_pairs, dim,
+                       b_broadcast, metric, out);
+    return hipGetLastError();
+}
+
+// queries handed over in device memory: gather into slot order, zero-padded to the row stride
+__global__ __launch_bounds__(256) void gather_queries_kernel(const float* src, const uint32_t* slot_query, uint32_t nq,
+                                                             uint32_t dim, uint32_t qfloats, float* dst)
+{
+    const uint32_t s = blockIdx.x;
+    const float* q = src + (size_t) slot_query[s] * dim;
+    for (uint32_t j = threadIdx.x; j < qfloats; j += 256) dst[(size_t) s * qfloats + j] = j < dim ? q[j] : 0.0f;
+}
+
+hipError_t launch_gather_queries(const float* src, const uint32_t* slot_query, uint32_t nq, uint32_t dim,
+                                 uint32_t qfloats, float* dst, hipStream_t s)
+{
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(nq), dim3(256), 0, s, src, slot_query, nq, dim, qfloats, dst);
+    return hipGetLastError();
+}
+
+}  // namespace vsr

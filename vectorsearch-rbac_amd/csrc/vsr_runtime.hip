@@ -1,0 +1,1050 @@
+// vsr_runtime.hip — host side of libvsrbac: the C ABI of include/vsrbac.h over the gfx950 kernels.
+// No CPU compute path: every search / distance entry point launches HIP kernels or fails.
+#include "../../include/vsrbac.h"
+#include "vsr_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace vsr;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int status, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? VSR_ERR_OOM : VSR_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// small RAII buffers (grow-only workspaces)
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return VSR_OK;
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t) 4096);
+        want += want / 4;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return VSR_OK;
+    }
+    void release()
+    {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PinBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return VSR_OK;
+        if (p) (void) hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t) 4096);
+        want += want / 4;
+        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return VSR_OK;
+    }
+    void release()
+    {
+        if (p) (void) hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;   // 0 = scan, 1 = select
+};
+
+struct vsr_ctx {
+    int             device = 0;
+    hipStream_t     stream = nullptr;
+    hipStream_t     own_stream = nullptr;
+    hipDeviceProp_t prop;
+    // workspaces
+    DevBuf d_desc;       // queries (padded) + q norms + scan groups + select queries, one upload
+    DevBuf d_partial;
+    DevBuf d_out;        // host-API outputs
+    DevBuf d_misc;
+    PinBuf h_desc;
+    PinBuf h_out;
+    hipEvent_t desc_done = nullptr;   // staging buffer reuse guard
+    bool desc_pending = false;
+    // measurement
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> event_pool;
+    vsr_stats stats{};
+    // knobs
+    int block_budget = 0;          // 0 = 4 * CUs
+    int min_rows_per_block = 256;
+    int max_qb = 4;
+};
+
+struct vsr_filter {
+    vsr_corpus* corpus = nullptr;
+    int         mode = VSR_FILTER_RANGES;
+    bool        cached = false;
+    uint2*      d_tiles = nullptr;     // RANGES
+    uint32_t    n_tiles = 0;
+    uint64_t*   d_bitmap = nullptr;    // BITMAP (or impure partition: tiles + bitmap)
+    bool        owns_bitmap = false;
+    int64_t     allowed_rows = 0;
+    int64_t     scanned_rows = 0;
+};
+
+struct vsr_corpus {
+    vsr_ctx*    ctx = nullptr;
+    int64_t     n = 0;
+    int         dim = 0;
+    uint32_t    stride4 = 0;
+    int64_t     row_offset = 0;
+    KernelShape shape{};
+    float4*     d_rows = nullptr;
+    float*      d_norm2 = nullptr;
+    int64_t*    d_block = nullptr;
+    int32_t*    d_doc = nullptr;
+    int64_t*    d_orig = nullptr;
+    uint32_t*   d_row_docidx = nullptr;
+    // host-side identity (internal order)
+    std::vector<int64_t> h_orig;
+    std::vector<int32_t> docs;            // sorted unique document ids
+    std::vector<uint32_t> doc_row_start;  // docs.size() + 1
+    // RBAC
+    bool rbac = false;
+    std::vector<int32_t> roles;           // sorted unique role ids
+    uint32_t words = 0;
+    std::vector<uint64_t> doc_mask;       // docs.size() * words
+    uint64_t* d_doc_mask = nullptr;
+    std::unordered_map<int32_t, std::vector<int32_t>> user_roles;
+    std::map<std::pair<int, std::vector<int32_t>>, vsr_filter*> cache;
+};
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int vsr_abi_version(void) { return VSR_ABI_VERSION; }
+
+extern "C" const char* vsr_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char* vsr_status_string(int s)
+{
+    switch (s) {
+    case VSR_OK: return "ok";
+    case VSR_ERR_INVALID: return "invalid argument";
+    case VSR_ERR_DIM_MISMATCH: return "different vector dimensions";
+    case VSR_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case VSR_ERR_HIP: return "HIP error";
+    case VSR_ERR_OOM: return "out of device memory";
+    case VSR_ERR_UNSUPPORTED: return "unsupported";
+    case VSR_ERR_NO_RBAC: return "RBAC tables not loaded";
+    default: return "unknown";
+    }
+}
+
+extern "C" int vsr_open(int device, vsr_ctx** out)
+{
+    if (!out) return fail(VSR_ERR_INVALID, "vsr_open: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(VSR_ERR_NO_DEVICE, "vsr_open: no HIP device (%s); libvsrbac has no CPU path",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(VSR_ERR_INVALID, "vsr_open: device %d of %d", device, count);
+    std::unique_ptr<vsr_ctx> ctx(new vsr_ctx());
+    ctx->device = device;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipGetDeviceProperties(&ctx->prop, device));
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(VSR_ERR_NO_DEVICE, "vsr_open: device %d is %s; this library is built for gfx950 only", device,
+                    ctx->prop.gcnArchName);
+    HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HIPCHK(hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming));
+    const char* env;
+    if ((env = getenv("VSR_BLOCK_BUDGET"))) ctx->block_budget = atoi(env);
+    if ((env = getenv("VSR_MIN_ROWS_PER_BLOCK"))) ctx->min_rows_per_block = std::max(1, atoi(env));
+    if ((env = getenv("VSR_MAX_QB"))) ctx->max_qb = std::max(1, atoi(env));
+    *out = ctx.release();
+    return VSR_OK;
+}
+
+extern "C" int vsr_close(vsr_ctx* ctx)
+{
+    if (!ctx) return VSR_OK;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    for (auto& ep : ctx->pending) {
+        (void) hipEventDestroy(ep.a);
+        (void) hipEventDestroy(ep.b);
+    }
+    for (auto ev : ctx->event_pool) (void) hipEventDestroy(ev);
+    ctx->d_desc.release();
+    ctx->d_partial.release();
+    ctx->d_out.release();
+    ctx->d_misc.release();
+    ctx->h_desc.release();
+    ctx->h_out.release();
+    if (ctx->desc_done) (void) hipEventDestroy(ctx->desc_done);
+    if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return VSR_OK;
+}
+
+extern "C" int vsr_set_stream(vsr_ctx* ctx, void* s)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_set_stream: ctx is NULL");
+    ctx->stream = s ? reinterpret_cast<hipStream_t>(s) : ctx->own_stream;
+    return VSR_OK;
+}
+
+extern "C" int vsr_synchronize(vsr_ctx* ctx)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_synchronize: ctx is NULL");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return VSR_OK;
+}
+
+extern "C" int vsr_device_info(vsr_ctx* ctx, char* name, int name_len, int* cus, int64_t* hbm)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_device_info: ctx is NULL");
+    if (name && name_len > 0) snprintf(name, (size_t) name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (cus) *cus = ctx->prop.multiProcessorCount;
+    if (hbm) *hbm = (int64_t) ctx->prop.totalGlobalMem;
+    return VSR_OK;
+}
+
+extern "C" int vsr_tune(vsr_ctx* ctx, int block_budget, int min_rows_per_block, int max_qb)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_tune: ctx is NULL");
+    if (block_budget >= 0) ctx->block_budget = block_budget;
+    if (min_rows_per_block > 0) ctx->min_rows_per_block = min_rows_per_block;
+    if (max_qb > 0) ctx->max_qb = max_qb;
+    return VSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------------
+static hipEvent_t take_event(vsr_ctx* ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void) hipEventCreate(&e);
+    return e;
+}
+
+static void drain_events(vsr_ctx* ctx)
+{
+    for (auto& ep : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            if (ep.kind == 0) {
+                ctx->stats.scan_ms += ms;
+                ctx->stats.scan_launches++;
+            } else {
+                ctx->stats.select_ms += ms;
+                ctx->stats.select_launches++;
+            }
+        }
+        ctx->event_pool.push_back(ep.a);
+        ctx->event_pool.push_back(ep.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" int vsr_profiling(vsr_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_profiling: ctx is NULL");
+    ctx->profiling = enable != 0;
+    return VSR_OK;
+}
+
+extern "C" int vsr_stats_get(vsr_ctx* ctx, vsr_stats* out)
+{
+    if (!ctx || !out) return fail(VSR_ERR_INVALID, "vsr_stats_get: NULL argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    *out = ctx->stats;
+    return VSR_OK;
+}
+
+extern "C" int vsr_stats_reset(vsr_ctx* ctx)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_stats_reset: ctx is NULL");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    ctx->stats = vsr_stats{};
+    return VSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// corpus
+// ---------------------------------------------------------------------------------------------
+extern "C" int vsr_corpus_free(vsr_corpus* c)
+{
+    if (!c) return VSR_OK;
+    (void) hipSetDevice(c->ctx->device);
+    (void) hipStreamSynchronize(c->ctx->stream);
+    for (auto& kv : c->cache) {
+        vsr_filter* f = kv.second;
+        if (f->d_tiles) (void) hipFree(f->d_tiles);
+        if (f->d_bitmap && f->owns_bitmap) (void) hipFree(f->d_bitmap);
+        delete f;
+    }
+    void* ptrs[] = {c->d_rows, c->d_norm2, c->d_block, c->d_doc, c->d_orig, c->d_row_docidx, c->d_doc_mask};
+    for (void* p : ptrs)
+        if (p) (void) hipFree(p);
+    delete c;
+    return VSR_OK;
+}
+
+extern "C" int64_t vsr_corpus_rows(const vsr_corpus* c) { return c ? c->n : 0; }
+extern "C" int vsr_corpus_dim(const vsr_corpus* c) { return c ? c->dim : 0; }
+
+extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int dim, const int64_t* block_ids,
+                               const int32_t* doc_ids, int64_t row_offset, vsr_corpus** out)
+{
+    if (!ctx || !out) return fail(VSR_ERR_INVALID, "vsr_corpus_load: NULL argument");
+    *out = nullptr;
+    if (n < 0 || (n > 0 && !rows)) return fail(VSR_ERR_INVALID, "vsr_corpus_load: rows is NULL");
+    if (dim < 1 || dim > 16000)      // VECTOR_MAX_DIM, pgvector/src/vector.h:4
+        return fail(VSR_ERR_INVALID, "vsr_corpus_load: vector must have between 1 and 16000 dimensions (got %d)", dim);
+    if (n + row_offset >= 0xFFFFFFFFll) return fail(VSR_ERR_UNSUPPORTED, "vsr_corpus_load: more than 2^32-2 rows per shard");
+    HIPCHK(hipSetDevice(ctx->device));
+
+    std::unique_ptr<vsr_corpus> c(new vsr_corpus());
+    c->ctx = ctx;
+    c->n = n;
+    c->dim = dim;
+    c->stride4 = (uint32_t) ((dim + 3) / 4);
+    c->row_offset = row_offset;
+    c->shape = scan_shape_for_dim(dim);
+
+    // internal order: (document_id, block_id); identity when the input is already sorted that way
+    std::vector<int64_t> perm((size_t) n);
+    std::iota(perm.begin(), perm.end(), (int64_t) 0);
+    auto doc_of = [&](int64_t r) { return doc_ids ? doc_ids[r] : 0; };
+    auto blk_of = [&](int64_t r) { return block_ids ? block_ids[r] : r; };
+    bool sorted = true;
+    for (int64_t i = 1; i < n && sorted; ++i) {
+        const int32_t da = doc_of(i - 1), db = doc_of(i);
+        if (da > db || (da == db && blk_of(i - 1) > blk_of(i))) sorted = false;
+    }
+    if (!sorted)
+        std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) {
+            const int32_t da = doc_of(a), db = doc_of(b);
+            if (da != db) return da < db;
+            return blk_of(a) < blk_of(b);
+        });
+    c->h_orig = perm;
+
+    std::vector<int32_t> h_doc((size_t) n);
+    std::vector<int64_t> h_blk((size_t) n);
+    std::vector<uint32_t> h_docidx((size_t) n);
+    for (int64_t i = 0; i < n; ++i) {
+        h_doc[(size_t) i] = doc_of(perm[(size_t) i]);
+        h_blk[(size_t) i] = blk_of(perm[(size_t) i]);
+        if (i == 0 || h_doc[(size_t) i] != h_doc[(size_t) i - 1]) {
+            c->docs.push_back(h_doc[(size_t) i]);
+            c->doc_row_start.push_back((uint32_t) i);
+        }
+        h_docidx[(size_t) i] = (uint32_t) (c->docs.size() - 1);
+    }
+    c->doc_row_start.push_back((uint32_t) n);
+
+    const size_t row_bytes = (size_t) c->stride4 * 16;
+    const size_t alloc_rows = (size_t) std::max<int64_t>(n, 1);
+    HIPCHK(hipMalloc(&c->d_rows, alloc_rows * row_bytes + 1024));
+    HIPCHK(hipMalloc(&c->d_norm2, alloc_rows * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_block, alloc_rows * sizeof(int64_t)));
+    HIPCHK(hipMalloc(&c->d_doc, alloc_rows * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&c->d_orig, alloc_rows * sizeof(int64_t)));
+    HIPCHK(hipMalloc(&c->d_row_docidx, alloc_rows * sizeof(uint32_t)));
+
+    if (n > 0) {
+        if (sorted && dim % 4 == 0) {
+            HIPCHK(hipMemcpy(c->d_rows, rows, (size_t) n * row_bytes, hipMemcpyHostToDevice));
+        } else {
+            // permute + zero-pad through a bounded host staging buffer
+            const size_t chunk_rows = std::max<size_t>(1, (64u << 20) / row_bytes);
+            std::vector<float> stage(chunk_rows * c->stride4 * 4);
+            for (int64_t base = 0; base < n; base += (int64_t) chunk_rows) {
+                const int64_t m = std::min<int64_t>((int64_t) chunk_rows, n - base);
+                std::fill(stage.begin(), stage.begin() + (size_t) m * c->stride4 * 4, 0.0f);
+                for (int64_t i = 0; i < m; ++i)
+                    memcpy(&stage[(size_t) i * c->stride4 * 4], rows + (size_t) perm[(size_t) (base + i)] * dim,
+                           (size_t) dim * sizeof(float));
+                HIPCHK(hipMemcpy(reinterpret_cast<char*>(c->d_rows) + (size_t) base * row_bytes, stage.data(),
+                                 (size_t) m * row_bytes, hipMemcpyHostToDevice));
+            }
+        }
+        HIPCHK(hipMemcpy(c->d_block, h_blk.data(), (size_t) n * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_doc, h_doc.data(), (size_t) n * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_orig, perm.data(), (size_t) n * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_row_docidx, h_docidx.data(), (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(launch_row_norms(c->d_rows, (uint32_t) n, c->stride4, c->d_norm2, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    *out = c.release();
+    return VSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RBAC
+// ---------------------------------------------------------------------------------------------
+static void drop_cached_filters(vsr_corpus* c)
+{
+    for (auto& kv : c->cache) {
+        vsr_filter* f = kv.second;
+        if (f->d_tiles) (void) hipFree(f->d_tiles);
+        if (f->d_bitmap && f->owns_bitmap) (void) hipFree(f->d_bitmap);
+        delete f;
+    }
+    c->cache.clear();
+}
+
+extern "C" int vsr_rbac_load(vsr_corpus* c, const int32_t* ur_user, const int32_t* ur_role, int64_t n_ur,
+                             const int32_t* pa_role, const int32_t* pa_doc, int64_t n_pa)
+{
+    if (!c) return fail(VSR_ERR_INVALID, "vsr_rbac_load: corpus is NULL");
+    if ((n_ur > 0 && (!ur_user || !ur_role)) || (n_pa > 0 && (!pa_role || !pa_doc)) || n_ur < 0 || n_pa < 0)
+        return fail(VSR_ERR_INVALID, "vsr_rbac_load: NULL table");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    HIPCHK(hipStreamSynchronize(c->ctx->stream));
+    drop_cached_filters(c);
+
+    c->roles.clear();
+    for (int64_t i = 0; i < n_ur; ++i) c->roles.push_back(ur_role[i]);
+    for (int64_t i = 0; i < n_pa; ++i) c->roles.push_back(pa_role[i]);
+    std::sort(c->roles.begin(), c->roles.end());
+    c->roles.erase(std::unique(c->roles.begin(), c->roles.end()), c->roles.end());
+    c->words = (uint32_t) std::max<size_t>(1, (c->roles.size() + 63) / 64);
+
+    c->user_roles.clear();
+    for (int64_t i = 0; i < n_ur; ++i) c->user_roles[ur_user[i]].push_back(ur_role[i]);
+    for (auto& kv : c->user_roles) {
+        std::sort(kv.second.begin(), kv.second.end());
+        kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+    }
+
+    c->doc_mask.assign(c->docs.size() * c->words, 0);
+    for (int64_t i = 0; i < n_pa; ++i) {
+        auto d = std::lower_bound(c->docs.begin(), c->docs.end(), pa_doc[i]);
+        if (d == c->docs.end() || *d != pa_doc[i]) continue;     // permission on a document with no rows here
+        const size_t di = (size_t) (d - c->docs.begin());
+        const size_t ri = (size_t) (std::lower_bound(c->roles.begin(), c->roles.end(), pa_role[i]) - c->roles.begin());
+        c->doc_mask[di * c->words + ri / 64] |= 1ull << (ri % 64);
+    }
+    if (c->d_doc_mask) (void) hipFree(c->d_doc_mask);
+    c->d_doc_mask = nullptr;
+    const size_t bytes = std::max<size_t>(8, c->doc_mask.size() * sizeof(uint64_t));
+    HIPCHK(hipMalloc(&c->d_doc_mask, bytes));
+    if (!c->doc_mask.empty())
+        HIPCHK(hipMemcpy(c->d_doc_mask, c->doc_mask.data(), c->doc_mask.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    c->rbac = true;
+    return VSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// filters
+// ---------------------------------------------------------------------------------------------
+static int upload_tiles(vsr_filter* f, const std::vector<uint2>& tiles)
+{
+    f->n_tiles = (uint32_t) tiles.size();
+    if (tiles.empty()) return VSR_OK;
+    HIPCHK(hipMalloc(&f->d_tiles, tiles.size() * sizeof(uint2)));
+    HIPCHK(hipMemcpy(f->d_tiles, tiles.data(), tiles.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    return VSR_OK;
+}
+
+// contiguous permitted row ranges -> tiles of <= RW rows
+static void ranges_to_tiles(const std::vector<std::pair<uint32_t, uint32_t>>& ranges, int rw, std::vector<uint2>& tiles)
+{
+    for (auto& r : ranges)
+        for (uint32_t s = r.first; s < r.second; s += (uint32_t) rw)
+            tiles.push_back(make_uint2(s, std::min<uint32_t>((uint32_t) rw, r.second - s)));
+}
+
+static size_t bitmap_words(int64_t n) { return (size_t) ((n + 63) / 64) + 2; }   // + pad for the 2-word window
+
+static int alloc_bitmap(vsr_filter* f)
+{
+    const size_t bytes = bitmap_words(f->corpus->n) * sizeof(uint64_t);
+    HIPCHK(hipMalloc(&f->d_bitmap, bytes));
+    HIPCHK(hipMemsetAsync(f->d_bitmap, 0, bytes, f->corpus->ctx->stream));
+    f->owns_bitmap = true;
+    return VSR_OK;
+}
+
+static void free_filter(vsr_filter* f)
+{
+    if (!f) return;
+    if (f->d_tiles) (void) hipFree(f->d_tiles);
+    if (f->d_bitmap && f->owns_bitmap) (void) hipFree(f->d_bitmap);
+    delete f;
+}
+
+static std::vector<uint64_t> role_mask(const vsr_corpus* c, const std::vector<int32_t>& roles)
+{
+    std::vector<uint64_t> m(c->words, 0);
+    for (int32_t r : roles) {
+        auto it = std::lower_bound(c->roles.begin(), c->roles.end(), r);
+        if (it == c->roles.end() || *it != r) continue;
+        const size_t ri = (size_t) (it - c->roles.begin());
+        m[ri / 64] |= 1ull << (ri % 64);
+    }
+    return m;
+}
+
+static bool doc_allowed(const vsr_corpus* c, size_t di, const std::vector<uint64_t>& m)
+{
+    for (uint32_t w = 0; w < c->words; ++w)
+        if (c->doc_mask[di * c->words + w] & m[w]) return true;
+    return false;
+}
+
+static int build_role_filter(vsr_corpus* c, const std::vector<int32_t>& roles, int mode, vsr_filter** out)
+{
+    std::unique_ptr<vsr_filter, void (*)(vsr_filter*)> f(new vsr_filter(), free_filter);
+    f->corpus = c;
+    f->mode = mode;
+    const std::vector<uint64_t> m = role_mask(c, roles);
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    int64_t allowed = 0;
+    for (size_t di = 0; di < c->docs.size(); ++di) {
+        if (!doc_allowed(c, di, m)) continue;
+        const uint32_t s = c->doc_row_start[di], e = c->doc_row_start[di + 1];
+        allowed += e - s;
+        if (!ranges.empty() && ranges.back().second == s) ranges.back().second = e;
+        else ranges.emplace_back(s, e);
+    }
+    f->allowed_rows = allowed;
+    if (mode == VSR_FILTER_RANGES) {
+        std::vector<uint2> tiles;
+        ranges_to_tiles(ranges, c->shape.rw, tiles);
+        int rc = upload_tiles(f.get(), tiles);
+        if (rc) return rc;
+        f->scanned_rows = allowed;
+    } else {
+        int rc = alloc_bitmap(f.get());
+        if (rc) return rc;
+        vsr_ctx* ctx = c->ctx;
+        rc = ctx->d_misc.reserve(c->words * sizeof(uint64_t));
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->d_misc.p, m.data(), c->words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(launch_build_bitmap(c->d_row_docidx, (uint32_t) c->n, c->d_doc_mask, c->words,
+                                   ctx->d_misc.as<uint64_t>(), f->d_bitmap, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));      // m is a stack-owned host buffer
+        f->n_tiles = (uint32_t) ((c->n + c->shape.rw - 1) / c->shape.rw);
+        f->scanned_rows = c->n;
+    }
+    *out = f.release();
+    return VSR_OK;
+}
+
+extern "C" int vsr_filter_for_roles(vsr_corpus* c, const int32_t* role_ids, int n_roles, int mode, vsr_filter** out)
+{
+    if (!c || !out || n_roles < 0 || (n_roles > 0 && !role_ids)) return fail(VSR_ERR_INVALID, "vsr_filter_for_roles: bad argument");
+    *out = nullptr;
+    if (mode != VSR_FILTER_RANGES && mode != VSR_FILTER_BITMAP) return fail(VSR_ERR_INVALID, "vsr_filter_for_roles: mode %d", mode);
+    if (!c->rbac) return fail(VSR_ERR_NO_RBAC, "vsr_filter_for_roles: call vsr_rbac_load first");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    std::vector<int32_t> roles(role_ids, role_ids + n_roles);
+    std::sort(roles.begin(), roles.end());
+    roles.erase(std::unique(roles.begin(), roles.end()), roles.end());
+    auto key = std::make_pair(mode, roles);
+    auto it = c->cache.find(key);
+    if (it != c->cache.end()) {
+        *out = it->second;
+        return VSR_OK;
+    }
+    vsr_filter* f = nullptr;
+    int rc = build_role_filter(c, roles, mode, &f);
+    if (rc) return rc;
+    f->cached = true;
+    c->cache[key] = f;
+    *out = f;
+    return VSR_OK;
+}
+
+extern "C" int vsr_filter_for_user(vsr_corpus* c, int32_t user_id, int mode, vsr_filter** out)
+{
+    if (!c || !out) return fail(VSR_ERR_INVALID, "vsr_filter_for_user: NULL argument");
+    if (!c->rbac) return fail(VSR_ERR_NO_RBAC, "vsr_filter_for_user: call vsr_rbac_load first");
+    auto it = c->user_roles.find(user_id);
+    static const std::vector<int32_t> none;
+    const std::vector<int32_t>& roles = it == c->user_roles.end() ? none : it->second;   // unknown user: sees nothing
+    return vsr_filter_for_roles(c, roles.data(), (int) roles.size(), mode, out);
+}
+
+extern "C" int vsr_filter_from_bytemask(vsr_corpus* c, const uint8_t* allowed, int mode, vsr_filter** out)
+{
+    if (!c || !out || (!allowed && c->n > 0)) return fail(VSR_ERR_INVALID, "vsr_filter_from_bytemask: NULL argument");
+    *out = nullptr;
+    if (mode != VSR_FILTER_RANGES && mode != VSR_FILTER_BITMAP) return fail(VSR_ERR_INVALID, "vsr_filter_from_bytemask: mode %d", mode);
+    HIPCHK(hipSetDevice(c->ctx->device));
+    std::unique_ptr<vsr_filter, void (*)(vsr_filter*)> f(new vsr_filter(), free_filter);
+    f->corpus = c;
+    f->mode = mode;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < c->n; ++i) cnt += allowed[i] != 0;
+    f->allowed_rows = cnt;
+    if (mode == VSR_FILTER_RANGES) {
+        std::vector<std::pair<uint32_t, uint32_t>> ranges;
+        for (int64_t i = 0; i < c->n; ++i) {
+            if (!allowed[c->h_orig[(size_t) i]]) continue;
+            if (!ranges.empty() && ranges.back().second == (uint32_t) i) ranges.back().second++;
+            else ranges.emplace_back((uint32_t) i, (uint32_t) i + 1);
+        }
+        std::vector<uint2> tiles;
+        ranges_to_tiles(ranges, c->shape.rw, tiles);
+        int rc = upload_tiles(f.get(), tiles);
+        if (rc) return rc;
+        f->scanned_rows = cnt;
+    } else {
+        int rc = alloc_bitmap(f.get());
+        if (rc) return rc;
+        vsr_ctx* ctx = c->ctx;
+        rc = ctx->d_misc.reserve((size_t) std::max<int64_t>(c->n, 1));
+        if (rc) return rc;
+        if (c->n > 0) {
+            HIPCHK(hipMemcpyAsync(ctx->d_misc.p, allowed, (size_t) c->n, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(launch_pack_bytemask(ctx->d_misc.as<uint8_t>(), c->d_orig, (uint32_t) c->n, f->d_bitmap, ctx->stream));
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        f->n_tiles = (uint32_t) ((c->n + c->shape.rw - 1) / c->shape.rw);
+        f->scanned_rows = c->n;
+    }
+    *out = f.release();
+    return VSR_OK;
+}
+
+extern "C" int vsr_filter_from_documents(vsr_corpus* c, const int32_t* doc_ids, int64_t n_docs, int32_t user_id,
+                                         vsr_filter** out)
+{
+    if (!c || !out || n_docs < 0 || (n_docs > 0 && !doc_ids)) return fail(VSR_ERR_INVALID, "vsr_filter_from_documents: bad argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(c->ctx->device));
+    std::unique_ptr<vsr_filter, void (*)(vsr_filter*)> f(new vsr_filter(), free_filter);
+    f->corpus = c;
+    f->mode = VSR_FILTER_RANGES;
+    std::vector<int32_t> want(doc_ids, doc_ids + n_docs);
+    std::sort(want.begin(), want.end());
+    want.erase(std::unique(want.begin(), want.end()), want.end());
+    std::vector<uint64_t> um;
+    if (user_id >= 0) {
+        if (!c->rbac) return fail(VSR_ERR_NO_RBAC, "vsr_filter_from_documents: call vsr_rbac_load first");
+        auto it = c->user_roles.find(user_id);
+        static const std::vector<int32_t> none;
+        um = role_mask(c, it == c->user_roles.end() ? none : it->second);
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    int64_t scanned = 0, allowed = 0;
+    for (int32_t d : want) {
+        auto it = std::lower_bound(c->docs.begin(), c->docs.end(), d);
+        if (it == c->docs.end() || *it != d) continue;
+        const size_t di = (size_t) (it - c->docs.begin());
+        const uint32_t s = c->doc_row_start[di], e = c->doc_row_start[di + 1];
+        scanned += e - s;
+        if (user_id < 0 || doc_allowed(c, di, um)) allowed += e - s;
+        if (!ranges.empty() && ranges.back().second == s) ranges.back().second = e;
+        else ranges.emplace_back(s, e);
+    }
+    std::vector<uint2> tiles;
+    ranges_to_tiles(ranges, c->shape.rw, tiles);
+    int rc = upload_tiles(f.get(), tiles);
+    if (rc) return rc;
+    f->allowed_rows = allowed;
+    f->scanned_rows = scanned;
+    if (user_id >= 0) {
+        // impure partition: the user's permission bitmap rides along with the partition's tiles
+        vsr_filter* ub = nullptr;
+        rc = vsr_filter_for_user(c, user_id, VSR_FILTER_BITMAP, &ub);
+        if (rc) return rc;
+        f->d_bitmap = ub->d_bitmap;
+        f->owns_bitmap = false;
+    }
+    *out = f.release();
+    return VSR_OK;
+}
+
+extern "C" int vsr_filter_free(vsr_filter* f)
+{
+    if (!f || f->cached) return VSR_OK;    // cached filters belong to the corpus
+    (void) hipSetDevice(f->corpus->ctx->device);
+    (void) hipStreamSynchronize(f->corpus->ctx->stream);
+    free_filter(f);
+    return VSR_OK;
+}
+
+extern "C" int64_t vsr_filter_allowed_rows(const vsr_filter* f) { return f ? f->allowed_rows : 0; }
+extern "C" int64_t vsr_filter_scanned_rows(const vsr_filter* f) { return f ? f->scanned_rows : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Plan {
+    std::vector<uint32_t>    slot_query;     // slot -> caller query index
+    std::vector<ScanGroup>   groups_qb[2];   // [0]: QB = 1 launch, [1]: QB = max_qb launch
+    uint32_t                 blocks_qb[2] = {0, 0};
+    std::vector<SelectQuery> selq;           // one per query (slot order)
+    uint32_t                 n_partial = 0;
+    int64_t                  scan_rows = 0;
+    int64_t                  scan_bytes = 0;
+};
+
+struct PassDesc {
+    const vsr_filter* f;
+    uint32_t q_begin, q_count;
+    int64_t rows;
+    uint32_t n_tiles;
+};
+
+}  // namespace
+
+static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* const* filters, Plan& plan)
+{
+    const vsr_ctx* ctx = c->ctx;
+    // queries sharing a filter share corpus passes: order slots by filter
+    std::vector<uint32_t> order((size_t) nq);
+    std::iota(order.begin(), order.end(), 0u);
+    auto fof = [&](uint32_t q) { return filters ? filters[q] : nullptr; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fof(a) < fof(b); });
+    plan.slot_query = order;
+
+    const int max_qb = std::min(ctx->max_qb, scan_max_qb(c->dim, k)) >= 4 ? 4 : 1;
+    std::vector<PassDesc> passes;
+    for (uint32_t s = 0; s < (uint32_t) nq;) {
+        const vsr_filter* f = fof(order[s]);
+        uint32_t e = s;
+        while (e < (uint32_t) nq && fof(order[e]) == f) ++e;
+        for (uint32_t b = s; b < e;) {
+            const uint32_t cnt = std::min<uint32_t>(e - b, (uint32_t) max_qb);
+            PassDesc pd;
+            pd.f = f;
+            pd.q_begin = b;
+            pd.q_count = cnt;
+            pd.rows = f ? f->scanned_rows : c->n;
+            pd.n_tiles = f ? f->n_tiles : (uint32_t) ((c->n + c->shape.rw - 1) / c->shape.rw);
+            passes.push_back(pd);
+            b += cnt;
+        }
+        s = e;
+    }
+
+    int64_t total_rows = 0;
+    for (auto& p : passes) total_rows += std::max<int64_t>(p.rows, 1);
+    const int64_t budget = ctx->block_budget > 0 ? ctx->block_budget : 4 * (int64_t) ctx->prop.multiProcessorCount;
+
+    plan.selq.resize((size_t) nq);
+    for (auto& p : passes) {
+        int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows - 1) / total_rows;
+        nb = std::min<int64_t>(nb, std::max<int64_t>(1, p.rows / ctx->min_rows_per_block));
+        nb = std::min<int64_t>(nb, std::max<uint32_t>(1, p.n_tiles));
+        nb = std::max<int64_t>(nb, 1);
+        const int li = p.q_count > 1 ? 1 : 0;
+        const bool empty = p.n_tiles == 0 || p.rows == 0;
+        for (uint32_t qi = 0; qi < p.q_count; ++qi) {
+            SelectQuery sq;
+            sq.partial_begin = plan.n_partial + qi * (uint32_t) nb;
+            sq.n_lists = empty ? 0 : (uint32_t) nb;
+            sq.out_slot = order[p.q_begin + qi];
+            sq.pad = 0;
+            plan.selq[p.q_begin + qi] = sq;
+        }
+        if (empty) continue;
+        ScanGroup g;
+        g.tiles = p.f && p.f->mode == VSR_FILTER_RANGES ? p.f->d_tiles : nullptr;
+        g.bitmap = p.f ? p.f->d_bitmap : nullptr;
+        g.n_tiles = p.n_tiles;
+        g.q_begin = p.q_begin;
+        g.q_count = p.q_count;
+        g.block_begin = plan.blocks_qb[li];
+        g.n_blocks = (uint32_t) nb;
+        g.partial_begin = plan.n_partial;
+        plan.groups_qb[li].push_back(g);
+        plan.blocks_qb[li] += (uint32_t) nb;
+        plan.n_partial += (uint32_t) nb * p.q_count;
+        plan.scan_rows += p.rows;
+        plan.scan_bytes += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12;
+    }
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Shared by the host and device entry points.  d_queries == nullptr: queries come from `h_queries`.
+static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_queries, int nq, int dim, int k, int metric,
+                       const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row, float* d_dist,
+                       int32_t* d_cnt, uint64_t* d_keys)
+{
+    vsr_ctx* ctx = c->ctx;
+    Plan plan;
+    make_plan(c, nq, k, filters, plan);
+
+    const uint32_t kp = (uint32_t) k;
+    const size_t qfloats = (size_t) c->stride4 * 4;
+    // one staging block: [queries | q_norm2 | groups(QB=1) | groups(QB=4) | select queries]
+    const size_t off_q = 0;
+    const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
+    const size_t off_g0 = align_up(off_qn + (size_t) nq * sizeof(float), 256);
+    const size_t off_g1 = align_up(off_g0 + plan.groups_qb[0].size() * sizeof(ScanGroup), 256);
+    const size_t off_sq = align_up(off_g1 + plan.groups_qb[1].size() * sizeof(ScanGroup), 256);
+    const size_t off_sl = align_up(off_sq + plan.selq.size() * sizeof(SelectQuery), 256);
+    const size_t total = align_up(off_sl + (size_t) nq * sizeof(uint32_t), 256);
+
+    int rc;
+    if ((rc = ctx->h_desc.reserve(total))) return rc;
+    if ((rc = ctx->d_desc.reserve(total))) return rc;
+    if ((rc = ctx->d_partial.reserve(std::max<size_t>(8, (size_t) plan.n_partial * kp * sizeof(uint64_t))))) return rc;
+    if (ctx->desc_pending) {
+        HIPCHK(hipEventSynchronize(ctx->desc_done));
+        ctx->desc_pending = false;
+    }
+    char* hs = ctx->h_desc.as<char>();
+    char* ds = ctx->d_desc.as<char>();
+    float* hq = reinterpret_cast<float*>(hs + off_q);
+    float* hqn = reinterpret_cast<float*>(hs + off_qn);
+    if (h_queries) {
+        for (int s = 0; s < nq; ++s) {
+            const float* src = h_queries + (size_t) plan.slot_query[(size_t) s] * dim;
+            float* dst = hq + (size_t) s * qfloats;
+            memcpy(dst, src, (size_t) dim * sizeof(float));
+            for (size_t j = (size_t) dim; j < qfloats; ++j) dst[j] = 0.0f;
+        }
+    }
+    memcpy(hs + off_g0, plan.groups_qb[0].data(), plan.groups_qb[0].size() * sizeof(ScanGroup));
+    memcpy(hs + off_g1, plan.groups_qb[1].data(), plan.groups_qb[1].size() * sizeof(ScanGroup));
+    memcpy(hs + off_sq, plan.selq.data(), plan.selq.size() * sizeof(SelectQuery));
+    memcpy(hs + off_sl, plan.slot_query.data(), (size_t) nq * sizeof(uint32_t));
+    if (h_queries) {
+        HIPCHK(hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(ds + off_g0, hs + off_g0, total - off_g0, hipMemcpyHostToDevice, ctx->stream));
+        // gather the caller's device queries into padded slot order
+        HIPCHK(launch_gather_queries(d_queries, reinterpret_cast<const uint32_t*>(ds + off_sl), (uint32_t) nq, (uint32_t) dim,
+                                     (uint32_t) qfloats, reinterpret_cast<float*>(ds + off_q), ctx->stream));
+    }
+    HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
+    ctx->desc_pending = true;
+    (void) hqn;
+
+    ScanParams sp;
+    sp.rows = c->d_rows;
+    sp.norm2 = c->d_norm2;
+    sp.n_rows = (uint32_t) c->n;
+    sp.stride4 = c->stride4;
+    sp.queries = reinterpret_cast<const float*>(ds + off_q);
+    sp.q_norm2 = reinterpret_cast<const float*>(ds + off_qn);
+    sp.partial = ctx->d_partial.as<uint64_t>();
+    sp.kp = kp;
+    sp.k = (uint32_t) k;
+    sp.cap = cap_for_k(k);
+    if (metric == VSR_METRIC_COSINE)   // |q|^2 with the same kernel that made the row norms
+        HIPCHK(launch_row_norms(reinterpret_cast<const float4*>(sp.queries), (uint32_t) nq, c->stride4,
+                                reinterpret_cast<float*>(ds + off_qn), ctx->stream));
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool any_scan = plan.blocks_qb[0] + plan.blocks_qb[1] > 0;
+    if (ctx->profiling && any_scan) {
+        e0 = take_event(ctx);
+        e1 = take_event(ctx);
+        HIPCHK(hipEventRecord(e0, ctx->stream));
+    }
+    for (int li = 0; li < 2; ++li) {
+        if (!plan.blocks_qb[li]) continue;
+        sp.groups = reinterpret_cast<const ScanGroup*>(ds + (li ? off_g1 : off_g0));
+        sp.n_groups = (uint32_t) plan.groups_qb[li].size();
+        HIPCHK(launch_scan(sp, metric, c->dim, li ? 4 : 1, plan.blocks_qb[li], ctx->stream));
+    }
+    if (e0) {
+        HIPCHK(hipEventRecord(e1, ctx->stream));
+        ctx->pending.push_back({e0, e1, 0});
+    }
+
+    SelectParams sel;
+    sel.partial = ctx->d_partial.as<uint64_t>();
+    sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
+    sel.kp = kp;
+    sel.k = (uint32_t) k;
+    sel.cap = 2048;
+    while (sel.cap < (uint32_t) (2 * k + SELECT_THREADS)) sel.cap <<= 1;
+    sel.metric = metric;
+    sel.row_offset = (uint32_t) c->row_offset;
+    sel.block_ids = c->d_block;
+    sel.doc_ids = c->d_doc;
+    sel.orig_rows = c->d_orig;
+    sel.out_block = d_blk;
+    sel.out_doc = d_doc;
+    sel.out_row = d_row;
+    sel.out_dist = d_dist;
+    sel.out_keys = d_keys;
+    sel.out_count = d_cnt;
+    hipEvent_t s0 = nullptr, s1 = nullptr;
+    if (ctx->profiling) {
+        s0 = take_event(ctx);
+        s1 = take_event(ctx);
+        HIPCHK(hipEventRecord(s0, ctx->stream));
+    }
+    HIPCHK(launch_select(sel, (uint32_t) nq, ctx->stream));
+    if (s0) {
+        HIPCHK(hipEventRecord(s1, ctx->stream));
+        ctx->pending.push_back({s0, s1, 1});
+    }
+    ctx->stats.scan_bytes += plan.scan_bytes;
+    ctx->stats.scan_rows += plan.scan_rows;
+    ctx->stats.queries += nq;
+    return VSR_OK;
+}
+
+static int check_search_args(const vsr_corpus* c, const void* queries, int nq, int dim, int k, int metric,
+                             const vsr_filter* const* filters, const char* who)
+{
+    if (!c) return fail(VSR_ERR_INVALID, "%s: corpus is NULL", who);
+    if (nq < 0 || (nq > 0 && !queries)) return fail(VSR_ERR_INVALID, "%s: queries is NULL", who);
+    if (dim != c->dim) return fail(VSR_ERR_DIM_MISMATCH, "different vector dimensions %d and %d", c->dim, dim);
+    if (k < 1) return fail(VSR_ERR_INVALID, "%s: k must be >= 1 (got %d)", who, k);
+    if (k > VSR_MAX_K) return fail(VSR_ERR_UNSUPPORTED, "%s: k = %d exceeds VSR_MAX_K = %d", who, k, VSR_MAX_K);
+    if (metric < VSR_METRIC_L2 || metric > VSR_METRIC_L1) return fail(VSR_ERR_INVALID, "%s: metric %d", who, metric);
+    if (filters)
+        for (int i = 0; i < nq; ++i)
+            if (filters[i] && filters[i]->corpus != c) return fail(VSR_ERR_INVALID, "%s: filter %d belongs to another corpus", who, i);
+    return VSR_OK;
+}
+
+extern "C" int vsr_search_device(vsr_corpus* c, const float* d_queries, int nq, int dim, int k, int metric,
+                                 const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row,
+                                 float* d_dist, int32_t* d_cnt, uint64_t* d_keys)
+{
+    int rc = check_search_args(c, d_queries, nq, dim, k, metric, filters, "vsr_search_device");
+    if (rc) return rc;
+    if (nq == 0) return VSR_OK;
+    if (!d_blk || !d_dist || !d_cnt) return fail(VSR_ERR_INVALID, "vsr_search_device: output is NULL");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    if (!d_doc) {
+        vsr_ctx* ctx = c->ctx;
+        if ((rc = ctx->d_misc.reserve((size_t) nq * k * sizeof(int32_t)))) return rc;
+        d_doc = ctx->d_misc.as<int32_t>();
+    }
+    return search_impl(c, nullptr, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys);
+}
+
+extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, int k, int metric,
+                          const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
+                          float* out_dist, int32_t* out_cnt)
+{
+    int rc = check_search_args(c, queries, nq, dim, k, metric, filters, "vsr_search");
+    if (rc) return rc;
+    if (nq == 0) return VSR_OK;
+    if (!out_blk || !out_dist || !out_cnt) return fail(VSR_ERR_INVALID, "vsr_search: output is NULL");
+    vsr_ctx* ctx = c->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nk = (size_t) nq * k;
+    const size_t o_blk = 0, o_row = align_up(o_blk + nk * 8, 256), o_doc = align_up(o_row + nk * 8, 256),
+                 o_dist = align_up(o_doc + nk * 4, 256), o_cnt = align_up(o_dist + nk * 4, 256),
+                 total = align_up(o_cnt + (size_t) nq * 4, 256);
+    if ((rc = ctx->d_out.reserve(total))) return rc;
+    if ((rc = ctx->h_out.reserve(total))) return rc;
+    char* d = ctx->d_out.as<char>();
+    rc = search_impl(c, queries, nullptr, nq, dim, k, metric, filters, reinterpret_cast<int64_t*>(d + o_blk),
+                     reinterpret_cast<int32_t*>(d + o_doc), reinterpret_cast<int64_t*>(d + o_row),
+                     reinterpret_cast<float*>(d + o_dist), reinterpret_cast<int32_t*>(d + o_cnt), nullptr);
+    if (rc) return rc;
+    char* h = ctx->h_out.as<char>();
+    HIPCHK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(out_blk, h + o_blk, nk * 8);
+    if (out_row) memcpy(out_row, h + o_row, nk * 8);
+    if (out_doc) memcpy(out_doc, h + o_doc, nk * 4);
+    memcpy(out_dist, h + o_dist, nk * 4);
+    memcpy(out_cnt, h + o_cnt, (size_t) nq * 4);
+    return VSR_OK;
+}
+
+extern "C" int vsr_merge_topk_device(vsr_ctx* ctx, const uint64_t* d_keys, const int64_t* d_blk, const int32_t* d_doc,
+                                     const float* d_dist, int n_parts, int nq, int k, int64_t* o_blk, int32_t* o_doc,
+                                     float* o_dist, uint64_t* o_keys, int32_t* o_cnt)
+{
+    if (!ctx || !d_keys || !d_blk || !d_doc || !d_dist || !o_blk || !o_doc || !o_dist || !o_cnt)
+        return fail(VSR_ERR_INVALID, "vsr_merge_topk_device: NULL argument");
+    if (n_parts < 1 || nq < 0 || k < 1) return fail(VSR_ERR_INVALID, "vsr_merge_topk_device: bad sizes");
+    if (nq == 0) return VSR_OK;
+    if ((int64_t) n_parts * k > 8192) return fail(VSR_ERR_UNSUPPORTED, "vsr_merge_topk_device: n_parts * k > 8192");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(launch_merge_lists(d_keys, d_blk, d_doc, d_dist, (uint32_t) n_parts, (uint32_t) nq, (uint32_t) k, o_blk,
+                              o_doc, o_dist, o_keys, o_cnt, ctx->stream));
+    return VSR_OK;
+}
+
+extern "C" int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, const float* b, int64_t n_pairs, int dim_a,
+                                  int dim_b, int b_broadcast, double* out)
+{
+    if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!a || !b || !out))) return fail(VSR_ERR_INVALID, "vsr_pair_distances: NULL argument");
+    if (dim_a != dim_b) return fail(VSR_ERR_DIM_MISMATCH, "different vector dimensions %d and %d", dim_a, dim_b);
+    if (dim_a < 1) return fail(VSR_ERR_INVALID, "vsr_pair_distances: dim %d", dim_a);
+    if (metric < VSR_METRIC_L2 || metric > VSR_METRIC_L1) return fail(VSR_ERR_INVALID, "vsr_pair_distances: metric %d", metric);
+    if (n_pairs == 0) return VSR_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t a_bytes = (size_t) n_pairs * dim_a * sizeof(float);
+    const size_t b_bytes = (size_t) (b_broadcast ? 1 : n_pairs) * dim_a * sizeof(float);
+    const size_t o_a = 0, o_b = align_up(a_bytes, 256), o_out = align_up(o_b + b_bytes, 256);
+    int rc = ctx->d_misc.reserve(o_out + (size_t) n_pairs * sizeof(double));
+    if (rc) return rc;
+    char* d = ctx->d_misc.as<char>();
+    HIPCHK(hipMemcpyAsync(d + o_a, a, a_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d + o_b, b, b_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(launch_pair_distances(reinterpret_cast<float*>(d + o_a), reinterpret_cast<float*>(d + o_b), n_pairs, dim_a,
+                                 b_broadcast, metric, reinterpret_cast<double*>(d + o_out), ctx->stream));
+    HIPCHK(hipMemcpyAsync(out, d + o_out, (size_t) n_pairs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return VSR_OK;
+}

@@ -1,0 +1,295 @@
+// vsr_scan.h — K1: fused distance + RBAC permission test + running top-k over corpus tiles.
+//
+// Replaces, for a whole ORDER BY <distance> LIMIT k scan, the per-row calls of
+//   pgvector/src/vector.c:549-563 VectorL2SquaredDistance / :596-606 VectorInnerProduct /
+//   :638-655 VectorCosineSimilarity / :714-724 VectorL1Distance
+// plus the top-N sort above them and the row-level-security predicate
+//   controller/baseline/pg_row_security/row_level_security.py:54-65 (as a per-row permission bit).
+//
+// Mapping (wave64): LPR lanes share one corpus row, each lane owning C float4 chunks of it, so one
+// wave load instruction reads 64/LPR rows as contiguous LPR*16-byte segments (1 KiB per instruction,
+// fully coalesced).  A wave iteration covers RW = R * 64/LPR rows with R*C independent 16-byte loads
+// in flight per lane; the query chunks a lane needs live in its registers (QB queries share the
+// pass).  Per-row partial sums are combined with a halving butterfly (R registers over LPR lanes),
+// after which lane (l % D == 0) owns the finished value of row slot l / D.
+// HBM-bound: 3 flop per 4 bytes; no MFMA on purpose.
+#pragma once
+#include "vsr_device.h"
+#include "vsr_topk.h"
+
+namespace vsr {
+
+template <int V> struct Log2 { static constexpr int value = 1 + Log2<V / 2>::value; };
+template <> struct Log2<1> { static constexpr int value = 0; };
+
+template <int METRIC>
+__device__ __forceinline__ void accum4(float& p, const float4& x, const float4& q)
+{
+    if constexpr (METRIC == M_L2) {
+        const float d0 = x.x - q.x, d1 = x.y - q.y, d2 = x.z - q.z, d3 = x.w - q.w;
+        p = fmaf(d0, d0, p); p = fmaf(d1, d1, p); p = fmaf(d2, d2, p); p = fmaf(d3, d3, p);
+    } else if constexpr (METRIC == M_L1) {
+        p += fabsf(x.x - q.x); p += fabsf(x.y - q.y); p += fabsf(x.z - q.z); p += fabsf(x.w - q.w);
+    } else {
+        p = fmaf(x.x, q.x, p); p = fmaf(x.y, q.y, p); p = fmaf(x.z, q.z, p); p = fmaf(x.w, q.w, p);
+    }
+}
+
+// fp32 ranking value, monotone in the SQL-level operator result:
+//   L2: the fp32 sum of squares (vector.c:584-594 ranks by it too); IP: -dot (vector.c:626-636);
+//   cosine: 1 - clamp(dot / sqrt(na*nb)) evaluated in double like vector.c:638-685; L1: the sum.
+template <int METRIC>
+__device__ __forceinline__ float rank_value(float p, float row_norm2, float q_norm2)
+{
+    if constexpr (METRIC == M_IP) {
+        return -p;
+    } else if constexpr (METRIC == M_COSINE) {
+        double sim = (double) p / sqrt((double) row_norm2 * (double) q_norm2);
+        if (sim > 1.0) sim = 1.0;
+        else if (sim < -1.0) sim = -1.0;
+        return (float) (1.0 - sim);
+    } else {
+        return p;
+    }
+}
+
+// Halving butterfly: N live registers over lanes differing in bit M (and below).
+template <int M, int N>
+__device__ __forceinline__ void reduce_slots(float* p, int lane)
+{
+    if constexpr (M >= 1) {
+        if constexpr (N > 1) {
+            const bool hi = (lane & M) != 0;
+#pragma unroll
+            for (int i = 0; i < N / 2; ++i) {
+                const float keep = hi ? p[i + N / 2] : p[i];
+                const float send = hi ? p[i] : p[i + N / 2];
+                p[i] = keep + __shfl_xor(send, M);
+            }
+            reduce_slots<M / 2, N / 2>(p, lane);
+        } else {
+            p[0] += __shfl_xor(p[0], M);
+            reduce_slots<M / 2, 1>(p, lane);
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t bitmap_window(const uint64_t* bm, uint32_t start)
+{
+    // the bitmap carries one zero pad word, so w + 1 is always readable
+    const uint32_t w = start >> 6, sh = start & 63;
+    uint64_t v = bm[w] >> sh;
+    if (sh) v |= bm[w + 1] << (64 - sh);
+    return v;
+}
+
+// C > 0: compile-time chunk count, queries in registers.
+// C == 0: runtime chunk loop (any dimension), queries in LDS; LPR must be 64.
+template <int METRIC, int LPR, int C, int R, int QB>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const ScanParams p)
+{
+    constexpr int G = 64 / LPR;                    // rows per load instruction
+    constexpr int RW = R * G;                      // rows per wave iteration
+    constexpr int H = Log2<R>::value < Log2<LPR>::value ? Log2<R>::value : Log2<LPR>::value;
+    constexpr int D = LPR >> H;                    // lanes holding the same finished value
+    constexpr int CC = C > 0 ? C : 1;
+    constexpr int XCHK = (APPEND_SLACK / (SCAN_WAVES * RW)) > 0 ? (APPEND_SLACK / (SCAN_WAVES * RW)) : 1;
+    static_assert(R <= LPR || LPR == 1, "one finished value per lane");
+    static_assert(SCAN_WAVES * RW * XCHK <= APPEND_SLACK, "append slack");
+    static_assert(RW <= 64, "tile rows fit one bitmap window");
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = lane % LPR;
+    const int g = lane / LPR;
+
+    // ---- which (filter, query chunk) does this workgroup serve ----
+    uint32_t lo = 0, hi = p.n_groups;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (p.groups[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const ScanGroup grp = p.groups[lo];
+    const uint32_t local_block = blockIdx.x - grp.block_begin;
+    const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
+    const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
+
+    const uint32_t cap = p.cap, k = p.k;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                       // [QB][cap]
+    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(keys + (size_t) QB * cap);   // [QB]
+    float4* qlds = reinterpret_cast<float4*>(ctrl + QB);                      // [QB][stride4], C == 0 only
+    if (tid < QB) {
+        ctrl[tid].tau = KEY_EMPTY;
+        ctrl[tid].count = 0;
+    }
+
+    // ---- queries ----
+    const uint32_t stride4 = p.stride4;
+    float4 q[QB][CC];
+    float qn[QB];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+        const uint32_t slot = grp.q_begin + ((uint32_t) qi < grp.q_count ? qi : 0);
+        const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
+        qn[qi] = (METRIC == M_COSINE) ? p.q_norm2[slot] : 0.0f;
+        if constexpr (C > 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const uint32_t chunk = c * LPR + l;
+                q[qi][c] = chunk < stride4 ? qsrc[chunk] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            for (uint32_t i = tid; i < stride4; i += SCAN_THREADS) qlds[(size_t) qi * stride4 + i] = qsrc[i];
+            q[qi][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    // the row this lane finishes after the butterfly
+    const bool own = (l % D) == 0;
+    const int row_own = (l / D) * G + g;
+    const uint32_t trigger = cap - APPEND_SLACK;
+    const uint32_t iters = (t1 - t0 + SCAN_WAVES - 1) / SCAN_WAVES;
+
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t t = t0 + it * SCAN_WAVES + wave;        // wave-uniform
+        if (t < t1) {
+            uint32_t start, nrows;
+            if (grp.tiles) {
+                const uint2 tl = grp.tiles[t];
+                start = tl.x;
+                nrows = tl.y;
+            } else {
+                start = t * RW;
+                nrows = p.n_rows - start < (uint32_t) RW ? p.n_rows - start : (uint32_t) RW;
+            }
+            uint64_t mask = nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
+            if (grp.bitmap) mask &= bitmap_window(grp.bitmap, start);
+            if (mask) {                                        // wave-uniform: skip fully masked tiles
+                const float4* base = p.rows + (size_t) start * stride4;
+                const bool ok_own = (mask >> row_own) & 1ull;
+                float rn = 0.0f;
+                if constexpr (METRIC == M_COSINE) {
+                    if (own && ok_own) rn = p.norm2[start + row_own];
+                }
+                float acc[QB][R];
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[qi][r] = 0.0f;
+
+                if constexpr (C > 0) {
+                    float4 x[R][C];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int row = r * G + g;
+                        const bool ok = (mask >> row) & 1ull;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const uint32_t chunk = c * LPR + l;
+                            x[r][c] = (ok && chunk < stride4) ? base[(size_t) row * stride4 + chunk]
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+#pragma unroll
+                            for (int qi = 0; qi < QB; ++qi) accum4<METRIC>(acc[qi][r], x[r][c], q[qi][c]);
+                } else {
+#pragma unroll 4
+                    for (uint32_t chunk = l; chunk < stride4; chunk += 64) {
+                        float4 x[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const bool ok = (mask >> r) & 1ull;
+                            x[r] = ok ? base[(size_t) r * stride4 + chunk] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int qi = 0; qi < QB; ++qi) {
+                            const float4 qv = qlds[(size_t) qi * stride4 + chunk];
+#pragma unroll
+                            for (int r = 0; r < R; ++r) accum4<METRIC>(acc[qi][r], x[r], qv);
+                        }
+                    }
+                }
+
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) {
+                    reduce_slots<LPR / 2, R>(acc[qi], lane);
+                    const float v = rank_value<METRIC>(acc[qi][0], rn, qn[qi]);
+                    const uint64_t key = make_key(v, start + row_own);
+                    const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[qi].tau);
+                    const bool pass = own && ok_own && ((uint32_t) qi < grp.q_count) && key < tau;
+                    topk_append(keys + (size_t) qi * cap, &ctrl[qi], pass, key);
+                }
+            }
+        }
+        if ((it % XCHK) == XCHK - 1 && it + 1 < iters) {       // workgroup-uniform
+            bool need = false;
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+                need |= *reinterpret_cast<volatile uint32_t*>(&ctrl[qi].count) > trigger;
+            if (__syncthreads_or(need)) {
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) topk_compact<SCAN_THREADS>(keys + (size_t) qi * cap, &ctrl[qi], k, tid, false);
+            }
+        }
+    }
+
+    // ---- publish this workgroup's k best per query ----
+    __syncthreads();
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+        topk_compact<SCAN_THREADS>(keys + (size_t) qi * cap, &ctrl[qi], k, tid, false);
+        if ((uint32_t) qi < grp.q_count) {
+            const uint32_t n = ctrl[qi].count < k ? ctrl[qi].count : k;
+            uint64_t* dst = p.partial + (size_t) (grp.partial_begin + qi * grp.n_blocks + local_block) * p.kp;
+            for (uint32_t i = tid; i < p.kp; i += SCAN_THREADS) dst[i] = i < n ? keys[(size_t) qi * cap + i] : KEY_EMPTY;
+        }
+    }
+}
+
+template <int METRIC, int LPR, int C, int R, int QB>
+hipError_t launch_scan_inst(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
+{
+    size_t lds = (size_t) QB * p.cap * sizeof(uint64_t) + (size_t) QB * sizeof(TopKCtrl);
+    if (C == 0) lds += (size_t) QB * p.stride4 * sizeof(float4);
+    auto kern = scan_kernel<METRIC, LPR, C, R, QB>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(SCAN_THREADS), lds, s, p);
+    return hipGetLastError();
+}
+
+// shape dispatch for one metric; instantiated once per metric in its own translation unit
+template <int METRIC>
+hipError_t launch_scan_metric(const ScanParams& p, int dim, int qb, uint32_t n_blocks, hipStream_t s)
+{
+    const KernelShape sh = scan_shape_for_dim(dim);
+#define VSR_CASE(LPR_, C_, R_)                                                             \
+    if (sh.lpr == LPR_ && sh.c == C_) {                                                    \
+        if (qb == 1) return launch_scan_inst<METRIC, LPR_, C_, R_, 1>(p, n_blocks, s);     \
+        if (qb == 4 && C_ != 0) return launch_scan_inst<METRIC, LPR_, C_, R_, (C_ != 0 ? 4 : 1)>(p, n_blocks, s); \
+        return hipErrorInvalidValue;                                                       \
+    }
+    VSR_CASE(1, 1, 1)
+    VSR_CASE(4, 1, 4)
+    VSR_CASE(16, 1, 8)
+    VSR_CASE(32, 1, 8)
+    VSR_CASE(64, 1, 8)
+    VSR_CASE(64, 2, 4)
+    VSR_CASE(64, 3, 4)
+    VSR_CASE(64, 4, 2)
+    VSR_CASE(64, 0, 2)
+#undef VSR_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace vsr

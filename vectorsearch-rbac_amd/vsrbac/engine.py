@@ -1,0 +1,226 @@
+"""Object wrappers over the C ABI: Context (one GPU), Corpus (resident rows + identity + RBAC), Filter."""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import VsrError, check, load_library
+
+L2, IP, COSINE, L1 = 0, 1, 2, 3
+METRICS = {"l2": L2, "<->": L2, "ip": IP, "<#>": IP, "cosine": COSINE, "<=>": COSINE, "l1": L1, "<+>": L1}
+RANGES, BITMAP = 0, 1
+
+SearchResult = namedtuple("SearchResult", "block_ids doc_ids rows dist counts")
+
+
+def _metric(m):
+    return METRICS[m] if isinstance(m, str) else int(m)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One MI355X.  Fails loudly (VsrError) when there is no gfx950 device."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        check(self._lib.vsr_open(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vsr_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int(), C.c_int64()
+        check(self._lib.vsr_device_info(self._h, name, 256, C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+    def set_stream(self, stream_handle):
+        check(self._lib.vsr_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def synchronize(self):
+        check(self._lib.vsr_synchronize(self._h))
+
+    def profiling(self, enable=True):
+        check(self._lib.vsr_profiling(self._h, int(bool(enable))))
+
+    def stats(self):
+        st = _ffi.Stats()
+        check(self._lib.vsr_stats_get(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+    def stats_reset(self):
+        check(self._lib.vsr_stats_reset(self._h))
+
+    def tune(self, block_budget=-1, min_rows_per_block=0, max_queries_per_pass=0):
+        check(self._lib.vsr_tune(self._h, block_budget, min_rows_per_block, max_queries_per_pass))
+
+    def load_corpus(self, rows, block_ids=None, doc_ids=None, row_offset=0):
+        return Corpus(self, rows, block_ids, doc_ids, row_offset)
+
+    def pair_distances(self, metric, a, b):
+        """Operator value for pairs (a[i], b[i]); b may be a single vector (broadcast).
+        Raises VsrError('different vector dimensions %d and %d') like pgvector's CheckDims."""
+        a = np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float32)))
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.float32))
+        bcast = b.ndim == 1
+        b2 = np.atleast_2d(b)
+        out = np.empty(a.shape[0], dtype=np.float64)
+        check(self._lib.vsr_pair_distances(self._h, _metric(metric), _ptr(a), _ptr(b2), a.shape[0],
+                                           a.shape[1], b2.shape[1], int(bcast), _ptr(out)))
+        return out
+
+    def merge_topk_device(self, keys, block_ids, doc_ids, dist, n_parts, nq, k, out_block, out_doc, out_dist,
+                          out_keys, out_counts):
+        """Device pointers (ints).  Layout [n_parts][nq][k]."""
+        check(self._lib.vsr_merge_topk_device(self._h, keys, block_ids, doc_ids, dist, n_parts, nq, k,
+                                              out_block, out_doc, out_dist, out_keys, out_counts))
+
+
+class Filter:
+    def __init__(self, corpus, handle, owned):
+        self.corpus = corpus
+        self._h = handle
+        self._owned = owned
+
+    @property
+    def allowed_rows(self):
+        return self.corpus._lib.vsr_filter_allowed_rows(self._h)
+
+    @property
+    def scanned_rows(self):
+        return self.corpus._lib.vsr_filter_scanned_rows(self._h)
+
+    def free(self):
+        if self._owned and self._h:
+            self.corpus._lib.vsr_filter_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            if self.corpus._h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Corpus:
+    """Rows resident in HBM, identified as (document_id, block_id) like the reference's documentblocks table."""
+
+    def __init__(self, ctx, rows, block_ids=None, doc_ids=None, row_offset=0):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2:
+            raise ValueError("rows must be [n, dim]")
+        n, dim = rows.shape
+        blk = None if block_ids is None else np.ascontiguousarray(block_ids, dtype=np.int64)
+        doc = None if doc_ids is None else np.ascontiguousarray(doc_ids, dtype=np.int32)
+        if (blk is not None and blk.size != n) or (doc is not None and doc.size != n):
+            raise ValueError("block_ids / doc_ids must have one entry per row")
+        h = C.c_void_p()
+        check(self._lib.vsr_corpus_load(ctx._h, _ptr(rows), n, dim, _ptr(blk), _ptr(doc), int(row_offset),
+                                        C.byref(h)))
+        self._h = h
+        self.n, self.dim = n, dim
+        self._user_filters = {}
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.vsr_corpus_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.free()
+        except Exception:
+            pass
+
+    # ---- RBAC -------------------------------------------------------------------------------
+    def load_rbac(self, user_roles, permissions):
+        """user_roles: (user_id, role_id) pairs; permissions: (role_id, document_id) pairs."""
+        ur = np.ascontiguousarray(np.asarray(user_roles, dtype=np.int32).reshape(-1, 2))
+        pa = np.ascontiguousarray(np.asarray(permissions, dtype=np.int32).reshape(-1, 2))
+        u, r = np.ascontiguousarray(ur[:, 0]), np.ascontiguousarray(ur[:, 1])
+        pr, pd = np.ascontiguousarray(pa[:, 0]), np.ascontiguousarray(pa[:, 1])
+        check(self._lib.vsr_rbac_load(self._h, _ptr(u), _ptr(r), len(ur), _ptr(pr), _ptr(pd), len(pa)))
+        self._user_filters = {}
+
+    def filter_for_user(self, user_id, mode=RANGES):
+        key = (int(user_id), int(mode))
+        f = self._user_filters.get(key)
+        if f is None:
+            h = C.c_void_p()
+            check(self._lib.vsr_filter_for_user(self._h, int(user_id), int(mode), C.byref(h)))
+            f = self._user_filters[key] = Filter(self, h, owned=False)
+        return f
+
+    def filter_for_roles(self, role_ids, mode=RANGES):
+        r = np.ascontiguousarray(role_ids, dtype=np.int32)
+        h = C.c_void_p()
+        check(self._lib.vsr_filter_for_roles(self._h, _ptr(r), r.size, int(mode), C.byref(h)))
+        return Filter(self, h, owned=False)
+
+    def filter_from_bytemask(self, allowed, mode=BITMAP):
+        m = np.ascontiguousarray(allowed, dtype=np.uint8)
+        if m.size != self.n:
+            raise ValueError("mask must have one byte per row")
+        h = C.c_void_p()
+        check(self._lib.vsr_filter_from_bytemask(self._h, _ptr(m), int(mode), C.byref(h)))
+        return Filter(self, h, owned=True)
+
+    def filter_from_documents(self, doc_ids, user_id=-1):
+        d = np.ascontiguousarray(doc_ids, dtype=np.int32)
+        h = C.c_void_p()
+        check(self._lib.vsr_filter_from_documents(self._h, _ptr(d), d.size, int(user_id), C.byref(h)))
+        return Filter(self, h, owned=True)
+
+    # ---- search ------------------------------------------------------------------------------
+    def _filter_array(self, filters, nq):
+        if filters is None:
+            return None, None
+        if isinstance(filters, Filter):
+            filters = [filters] * nq
+        if len(filters) != nq:
+            raise ValueError("one filter per query")
+        arr = (C.c_void_p * nq)(*[(f._h if f is not None else None) for f in filters])
+        return arr, filters
+
+    def search(self, queries, k, metric="l2", filters=None):
+        """Host buffers in and out.  Returns SearchResult of [nq, k] arrays (+ counts[nq])."""
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries, dtype=np.float32)))
+        nq, dim = q.shape
+        farr, keep = self._filter_array(filters, nq)
+        kk = max(int(k), 1)
+        blk = np.full((nq, kk), -1, dtype=np.int64)
+        doc = np.full((nq, kk), -1, dtype=np.int32)
+        row = np.full((nq, kk), -1, dtype=np.int64)
+        dist = np.full((nq, kk), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.int32)
+        check(self._lib.vsr_search(self._h, _ptr(q), nq, dim, int(k), _metric(metric), farr, _ptr(blk), _ptr(doc),
+                                   _ptr(row), _ptr(dist), _ptr(cnt)))
+        del keep
+        return SearchResult(blk, doc, row, dist, cnt)
+
+    def search_device(self, d_queries, nq, k, metric, filters, d_block, d_doc, d_rows, d_dist, d_counts, d_keys=None,
+                      dim=None):
+        """Device pointers (ints); enqueues on the context's stream, does not synchronise."""
+        farr, keep = self._filter_array(filters, nq)
+        check(self._lib.vsr_search_device(self._h, d_queries, nq, self.dim if dim is None else dim, int(k),
+                                          _metric(metric), farr, d_block, d_doc, d_rows, d_dist, d_counts, d_keys))
+        return keep
