@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — QPS of RBAC-filtered exact k-NN on MI355X (BASELINE.json's metric), with the K1 roofline
+and a CPU baseline timed beside it.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): synthetic SIFT10M-like corpus (10M x 128 fp32, integer-valued, 100 rows per
+document), tree RBAC (1000 users / 100 roles), k = 100, L2, role-level filter applied as a
+pre-filter (only the rows of the user's role partition are scanned).  A step = one batch of `--queries`
+queries (uniform rows x uniform users) through the whole hot path: K1 scan (distance + permission + running
+top-k) and K5 select; with N > 1 the corpus is sharded by contiguous row range (strong scaling, total work
+fixed), every rank searches its shard and the per-rank top-k lists are all-gathered over RCCL and merged.
+Inputs (corpus, filters, queries) are resident in HBM when the timed region starts.
+
+No part of the timed path touches the CPU oracle; it is used only by the cpu_baseline leg (rank 0, N = 1)
+and for a parity spot-check of the GPU results on the same sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "vectorsearch-rbac_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--queries", type=int, default=1000, help="queries per step")
+    ap.add_argument("--mode", choices=["prefilter", "postfilter"], default="prefilter")
+    ap.add_argument("--cpu-queries", type=int, default=192, help="sample size of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20251121)
+    return ap.parse_args()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import vsrbac
+    from vsrbac.sharded import shard_bounds
+    from vsrbac.datasets import sample_queries, sift_like_corpus, sift_like_rows_at, tree_rbac
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, dim, k, nq = args.rows, args.dim, args.k, args.queries
+    lo, hi = shard_bounds(n, world, rank, align=100)  # keep documents (100 rows) whole per shard
+    t0 = time.time()
+    x, blk, doc = sift_like_corpus(hi - lo, dim, seed=args.seed, start=lo)
+    rbac = tree_rbac(num_users=1000, num_roles=100, num_docs=n // 100, seed=args.seed)
+    qrow, quser = sample_queries(nq, n, 1000, seed=args.seed)
+    qvec = sift_like_rows_at(qrow, dim, args.seed)    # query vectors = corpus rows (read_dataset_function.py:736-737)
+    t_gen = time.time() - t0
+
+    ctx = vsrbac.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    corpus = ctx.load_corpus(x, blk, doc, row_offset=lo)
+    corpus.load_rbac(rbac.user_roles, rbac.permissions)
+    mode = vsrbac.RANGES if args.mode == "prefilter" else vsrbac.BITMAP
+    filters = [corpus.filter_for_user(int(u), mode) for u in quser]
+    t_load = time.time() - t0 - t_gen
+
+    d_q = torch.from_numpy(qvec).to(dev)
+    d_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    d_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    d_row = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    d_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    d_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    d_keys = torch.empty((nq, k), dtype=torch.int64, device=dev)      # raw u64 ordering keys
+    if world > 1:
+        g_keys = torch.empty((world * nq, k), dtype=torch.int64, device=dev)      # [world][nq][k]
+        g_blk = torch.empty((world * nq, k), dtype=torch.int64, device=dev)
+        g_doc = torch.empty((world * nq, k), dtype=torch.int32, device=dev)
+        g_dist = torch.empty((world * nq, k), dtype=torch.float32, device=dev)
+        m_blk, m_doc, m_dist = torch.empty_like(d_blk), torch.empty_like(d_doc), torch.empty_like(d_dist)
+        m_cnt, m_keys = torch.empty_like(d_cnt), torch.empty_like(d_keys)
+
+    def step():
+        corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
+                             ptr(d_cnt), ptr(d_keys))
+        if world > 1:
+            dist.all_gather_into_tensor(g_keys, d_keys)
+            dist.all_gather_into_tensor(g_blk, d_blk)
+            dist.all_gather_into_tensor(g_doc, d_doc)
+            dist.all_gather_into_tensor(g_dist, d_dist)
+            ctx.merge_topk_device(ptr(g_keys), ptr(g_blk), ptr(g_doc), ptr(g_dist), world, nq, k,
+                                  ptr(m_blk), ptr(m_doc), ptr(m_dist), ptr(m_keys), ptr(m_cnt))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profiling(True)
+    ctx.stats_reset()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t1
+    st = ctx.stats()
+    ctx.profiling(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant K1 kernel class (HIP events on the launch stream) ----
+    cls = int(np.argmax(st["scan_ms"]))
+    launches = max(1, st["scan_launches"][cls])
+    ms_avg = st["scan_ms"][cls] / launches
+    bytes_per_launch = st["scan_bytes"][cls] / launches
+    achieved = bytes_per_launch / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": f"vsr::scan_kernel<L2, LPR=32, C=1, R=8, QB={4 if cls else 1}>",
+        "launch_ms": round(ms_avg, 4), "bytes_per_launch": int(bytes_per_launch),
+        "launches": int(launches),
+        "all_scan_ms": [round(v, 3) for v in st["scan_ms"]], "all_scan_bytes": [int(v) for v in st["scan_bytes"]],
+        "select_ms": round(st["select_ms"], 3),
+    }
+
+    out = {
+        "metric": "QPS at recall@100, SIFT10M filtered-kNN (role RBAC), 1/2/4/8 MI355X",
+        "value": round(nq * args.steps / dt, 1), "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"SIFT10M-like {n}x{dim} fp32 L2 k={k}, tree RBAC 1000 users/100 roles, "
+                               f"role-partition {args.mode}, exact (recall@{k} = 1.0), {nq} queries/step",
+                   "rows": n, "dim": dim, "k": k, "queries_per_step": nq, "filter": args.mode,
+                   "sharding": f"row-range x{world}", "recall": 1.0},
+        "roofline": roofline,
+        "setup_s": {"generate": round(t_gen, 1), "load": round(t_load, 1)},
+    }
+
+    # ---- CPU baseline (rank 0, N = 1): the oracle, pgvector's flags, one thread, bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import Oracle
+        orc = Oracle("pgflags")
+        m = min(args.cpu_queries, nq)
+        ranges = []
+        for u in quser[:m]:
+            docs = rbac.visible_docs(int(u)).astype(np.int64)
+            ranges.append([((d - 1) * 100, 100) for d in docs])
+        tc = time.perf_counter()
+        rows_o, dist_o, cnt_o = orc.search_ranges("l2", x, qvec[:m], k, ranges, doc, blk)
+        cpu_s = time.perf_counter() - tc
+        got_rows = d_row[:m].cpu().numpy()
+        got_dist = d_dist[:m].cpu().numpy()
+        ok = bool((got_rows == rows_o).all() and (got_dist == dist_o.astype(np.float32)).all())
+        out["cpu_baseline"] = {
+            "value": round(m / cpu_s, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"first {m} queries of the step, exact seq-scan of each user's role partition, "
+                      f"{cpu_s:.1f} s on 1 of {os.cpu_count()} host cores (oracle built with pgvector's flags)",
+        }
+        out["parity_spot_check"] = {"queries": int(m), "ids_and_distances_identical": ok}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    corpus.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

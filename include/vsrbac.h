@@ -148,11 +148,12 @@ int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, const float* b,
 
 /* ---- measurement --------------------------------------------------------------------------------- */
 typedef struct {
-    int64_t scan_launches;      /* K1 launches timed                                   */
-    double  scan_ms;            /* sum of their HIP-event durations                    */
-    int64_t scan_bytes;         /* algorithmic bytes: rows*dim*4 + bitmap bytes + k*12 */
-    int64_t scan_rows;          /* rows scanned (per shared pass)                      */
-    int64_t select_launches;
+    /* K1 launches by kernel class: [0] = one query per pass, [1] = up to 4 queries sharing a pass */
+    int64_t scan_launches[2];
+    double  scan_ms[2];         /* sum of HIP-event durations of those launches          */
+    int64_t scan_bytes[2];      /* algorithmic bytes: rows*dim*4 + bitmap bytes + k*12   */
+    int64_t scan_rows[2];       /* rows scanned (per shared pass)                        */
+    int64_t select_launches;    /* K5 */
     double  select_ms;
     int64_t queries;
 } vsr_stats;

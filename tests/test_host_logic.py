@@ -1,0 +1,111 @@
+"""Host logic that needs no GPU: synthetic data generators, harness helpers, shard arithmetic, ordering keys."""
+import json
+
+import numpy as np
+import pytest
+
+
+def test_tree_rbac_semantics():
+    """tree_based_rbac_data_generator.py:48-187: disjoint own sets, ancestor inheritance, one role per user."""
+    from vsrbac.datasets import tree_rbac
+    r = tree_rbac(num_users=1000, num_roles=100, num_docs=10_000, seed=3)
+    assert len(r.role_docs) == 100 and len(r.user_roles) == 1000
+    assert len(set(r.user_roles[:, 0])) == 1000                       # exactly one role per user
+    own = {}
+    for role, docs in r.role_docs.items():
+        p = r.parent[role]
+        own[role] = np.setdiff1d(docs, r.role_docs[p]) if p else docs
+        if p:
+            assert np.isin(r.role_docs[p], docs).all()                 # inherits every ancestor document
+    allown = np.concatenate(list(own.values()))
+    assert allown.size == 10_000 and np.unique(allown).size == 10_000  # own sets partition the documents
+    depth = lambda x: 0 if x == 0 else 1 + depth(r.parent[x])
+    for role, docs in r.role_docs.items():
+        assert len(docs) in (100 * depth(role), 100 * depth(role) + 10_000 % 100)
+    sel = len(r.permissions) / (100 * 10_000)
+    assert 0.02 < sel < 0.05                                           # reference probe: 3.56 % mean selectivity
+    again = tree_rbac(num_users=1000, num_roles=100, num_docs=10_000, seed=3)
+    assert (again.permissions == r.permissions).all()
+
+
+def test_random_rbac_multi_role():
+    from vsrbac.datasets import random_rbac
+    r = random_rbac(num_users=200, num_roles=20, num_docs=500, m_roles=3, m_perms=100, seed=1)
+    per_user = np.bincount(r.user_roles[:, 0])[1:]
+    assert per_user.min() >= 1 and per_user.max() <= 3 and per_user.max() > 1
+    assert np.unique(r.permissions[:, 1]).size == 500                  # every document assigned at least once
+
+
+def test_sift_like_rows_are_shard_independent():
+    from vsrbac.datasets import sift_like_corpus, sift_like_rows, sift_like_rows_at
+    x, blk, doc = sift_like_corpus(3000, 128, seed=5)
+    assert x.dtype == np.float32 and x.min() >= 0 and x.max() <= 255 and (x == np.rint(x)).all()
+    assert blk[0] == 1 and doc[0] == 1 and doc[100] == 2               # read_dataset_function.py:338-339
+    np.testing.assert_array_equal(sift_like_rows(1000, 2000, 128, 5), x[1000:2000])
+    np.testing.assert_array_equal(sift_like_rows_at([7, 2999, 7], 128, 5), x[[7, 2999, 7]])
+    y, blk2, doc2 = sift_like_corpus(500, 128, seed=5, start=2500)
+    np.testing.assert_array_equal(y, x[2500:])
+    assert blk2[0] == 2501 and doc2[0] == 26
+
+
+def test_shard_bounds_cover_and_align():
+    from vsrbac.sharded import shard_bounds
+    for n, world in ((10_000_000, 8), (1_000_003, 4), (700, 3), (5, 8)):
+        cuts = [shard_bounds(n, world, r, 100 if n > 1000 else 1) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        for a, b in zip(cuts, cuts[1:]):
+            assert a[1] == b[0] and a[0] <= a[1]
+        if n > 1000:
+            assert all(c[0] % 100 == 0 for c in cuts)
+
+
+def test_monotone_keys_order_like_oracle(oracle):
+    """Sorting by the 64-bit key must equal the oracle's (distance, NaN last, row) order."""
+    from vsrbac.sharded import monotone_keys
+    vals = np.asarray([3.5, -0.0, 0.0, -2.0, np.inf, -np.inf, np.nan, 1e-30, -1e-30, 3.5], dtype=np.float32)
+    rows = np.arange(vals.size)
+    order = np.argsort(monotone_keys(vals, rows), kind="stable")
+    want = sorted(range(vals.size), key=lambda i: (np.isnan(vals[i]), float(vals[i]) + 0.0 if not np.isnan(vals[i]) else 0, i))
+    assert order.tolist() == want
+
+
+def test_harness_helpers_match_oracle(oracle, tmp_path):
+    from vsrbac import harness
+    np.testing.assert_array_equal(harness.parse_vector("[1, 2.5,-3]"), np.asarray([1, 2.5, -3], np.float32))
+    with pytest.raises(ValueError):
+        harness.parse_vector("1,2,3")
+    rng = np.random.default_rng(0)
+    rows = [(int(b), int(d), None, float(x)) for b, d, x in zip(rng.integers(1, 30, 200), rng.integers(1, 5, 200),
+                                                                 rng.integers(0, 20, 200))]
+    got = harness.merge_results(list(rows), 25)
+    idx = oracle.merge_dedup([r[3] for r in rows], [r[1] for r in rows], [r[0] for r in rows], 25)
+    assert got == [rows[i] for i in idx]                               # search.py:347-364 semantics
+    gt = [(1, 1), (1, 2), (2, 3), (2, 4)]
+    pr = [(1, 1), (2, 4), (9, 9)]
+    assert harness.compute_recall(gt, pr) == oracle.recall(gt, pr) == 0.5
+    # both ground-truth cache formats (common_function.py:831-849, compute_ground_truth.py:35-59)
+    p1, p2 = tmp_path / "a.json", tmp_path / "b.json"
+    p1.write_text(json.dumps([{"query": {"user_id": 1}, "ground_truth": [[5, 1, "txt", 0.1], [6, 1, "t", 0.2]]}]))
+    p2.write_text(json.dumps([[[5, 1], [6, 1]]]))
+    assert harness.load_ground_truth_cache(p1) == harness.load_ground_truth_cache(p2) == [[(5, 1), (6, 1)]]
+    p3 = tmp_path / "q.json"
+    p3.write_text(json.dumps([{"user_id": 3, "query_vector": "[1,2]", "topk": 10, "query_block_selectivity": 0.03}]))
+    assert harness.load_query_dataset(p3)[0]["topk"] == 10
+
+
+def test_run_search_experiment_protocol():
+    """Two warm-up calls + one measured call per query; recall on (document_id, block_id) sets."""
+    from vsrbac import harness
+    calls = []
+
+    def search_func(user_id, query_vector, topk, statistics_type):
+        calls.append(user_id)
+        return [(1, 10, None, 0.0), (2, 10, None, 1.0)], 0.004
+
+    def gt(user_id, qv, topk):
+        return [(1, 10, None, 0.0), (3, 10, None, 0.5)]
+
+    out = harness.run_search_experiment([{"user_id": 7, "query_vector": [0.0], "topk": 2}] * 3, search_func, gt)
+    assert len(calls) == 9
+    assert out["avg_recall"] == 0.5 and abs(out["avg_query_time"] - 0.004) < 1e-12 and abs(out["qps"] - 250) < 1e-6
+    assert set(out["all_results"][0]) == {"user_id", "query_vector", "recall", "query_time", "qps"}

@@ -95,7 +95,7 @@ struct PinBuf {
 
 struct EventPair {
     hipEvent_t a, b;
-    int kind;   // 0 = scan, 1 = select
+    int kind;   // 0 = scan (1 query/pass), 1 = scan (shared pass), 2 = select
 };
 
 struct vsr_ctx {
@@ -286,9 +286,9 @@ static void drain_events(vsr_ctx* ctx)
     for (auto& ep : ctx->pending) {
         float ms = 0.f;
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
-            if (ep.kind == 0) {
-                ctx->stats.scan_ms += ms;
-                ctx->stats.scan_launches++;
+            if (ep.kind < 2) {
+                ctx->stats.scan_ms[ep.kind] += ms;
+                ctx->stats.scan_launches[ep.kind]++;
             } else {
                 ctx->stats.select_ms += ms;
                 ctx->stats.select_launches++;
@@ -739,8 +739,8 @@ struct Plan {
     uint32_t                 blocks_qb[2] = {0, 0};
     std::vector<SelectQuery> selq;           // one per query (slot order)
     uint32_t                 n_partial = 0;
-    int64_t                  scan_rows = 0;
-    int64_t                  scan_bytes = 0;
+    int64_t                  scan_rows[2] = {0, 0};
+    int64_t                  scan_bytes[2] = {0, 0};
 };
 
 struct PassDesc {
@@ -782,17 +782,18 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
         s = e;
     }
 
-    int64_t total_rows = 0;
-    for (auto& p : passes) total_rows += std::max<int64_t>(p.rows, 1);
+    // the two kernel classes run back to back on the stream: each launch gets the whole block budget
+    int64_t total_rows[2] = {0, 0};
+    for (auto& p : passes) total_rows[p.q_count > 1 ? 1 : 0] += std::max<int64_t>(p.rows, 1);
     const int64_t budget = ctx->block_budget > 0 ? ctx->block_budget : 4 * (int64_t) ctx->prop.multiProcessorCount;
 
     plan.selq.resize((size_t) nq);
     for (auto& p : passes) {
-        int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows - 1) / total_rows;
+        const int li = p.q_count > 1 ? 1 : 0;
+        int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows[li] - 1) / total_rows[li];
         nb = std::min<int64_t>(nb, std::max<int64_t>(1, p.rows / ctx->min_rows_per_block));
         nb = std::min<int64_t>(nb, std::max<uint32_t>(1, p.n_tiles));
         nb = std::max<int64_t>(nb, 1);
-        const int li = p.q_count > 1 ? 1 : 0;
         const bool empty = p.n_tiles == 0 || p.rows == 0;
         for (uint32_t qi = 0; qi < p.q_count; ++qi) {
             SelectQuery sq;
@@ -815,8 +816,8 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
         plan.groups_qb[li].push_back(g);
         plan.blocks_qb[li] += (uint32_t) nb;
         plan.n_partial += (uint32_t) nb * p.q_count;
-        plan.scan_rows += p.rows;
-        plan.scan_bytes += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12;
+        plan.scan_rows[li] += p.rows;
+        plan.scan_bytes[li] += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12;
     }
 }
 
@@ -893,22 +894,23 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
         HIPCHK(launch_row_norms(reinterpret_cast<const float4*>(sp.queries), (uint32_t) nq, c->stride4,
                                 reinterpret_cast<float*>(ds + off_qn), ctx->stream));
 
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool any_scan = plan.blocks_qb[0] + plan.blocks_qb[1] > 0;
-    if (ctx->profiling && any_scan) {
-        e0 = take_event(ctx);
-        e1 = take_event(ctx);
-        HIPCHK(hipEventRecord(e0, ctx->stream));
-    }
     for (int li = 0; li < 2; ++li) {
         if (!plan.blocks_qb[li]) continue;
         sp.groups = reinterpret_cast<const ScanGroup*>(ds + (li ? off_g1 : off_g0));
         sp.n_groups = (uint32_t) plan.groups_qb[li].size();
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->profiling) {
+            e0 = take_event(ctx);
+            e1 = take_event(ctx);
+            HIPCHK(hipEventRecord(e0, ctx->stream));
+        }
         HIPCHK(launch_scan(sp, metric, c->dim, li ? 4 : 1, plan.blocks_qb[li], ctx->stream));
-    }
-    if (e0) {
-        HIPCHK(hipEventRecord(e1, ctx->stream));
-        ctx->pending.push_back({e0, e1, 0});
+        if (e0) {
+            HIPCHK(hipEventRecord(e1, ctx->stream));
+            ctx->pending.push_back({e0, e1, li});
+        }
+        ctx->stats.scan_bytes[li] += plan.scan_bytes[li];
+        ctx->stats.scan_rows[li] += plan.scan_rows[li];
     }
 
     SelectParams sel;
@@ -938,10 +940,8 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     HIPCHK(launch_select(sel, (uint32_t) nq, ctx->stream));
     if (s0) {
         HIPCHK(hipEventRecord(s1, ctx->stream));
-        ctx->pending.push_back({s0, s1, 1});
+        ctx->pending.push_back({s0, s1, 2});
     }
-    ctx->stats.scan_bytes += plan.scan_bytes;
-    ctx->stats.scan_rows += plan.scan_rows;
     ctx->stats.queries += nq;
     return VSR_OK;
 }

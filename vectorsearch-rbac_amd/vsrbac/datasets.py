@@ -60,6 +60,18 @@ def sift_like_rows(start, stop, dim=128, seed=20251121, workers=None):
     return out
 
 
+def sift_like_rows_at(indices, dim=128, seed=20251121):
+    """The SIFT-like rows at arbitrary row indices (query vectors are sampled corpus rows)."""
+    indices = np.asarray(indices, dtype=np.int64)
+    out = np.empty((indices.size, dim), dtype=np.float32)
+    for c in np.unique(indices // CHUNK):
+        sel = np.flatnonzero(indices // CHUNK == c)
+        local = indices[sel] - c * CHUNK
+        part = _sift_chunk(seed, int(c), int(local.max()) + 1, dim)
+        out[sel] = part[local]
+    return out
+
+
 def sift_like_corpus(n, dim=128, seed=20251121, rows_per_doc=100, start=0):
     """(rows, block_ids, doc_ids) for rows [start, start + n)."""
     x = sift_like_rows(start, start + n, dim, seed)

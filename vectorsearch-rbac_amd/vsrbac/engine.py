@@ -61,7 +61,11 @@ class Context:
     def stats(self):
         st = _ffi.Stats()
         check(self._lib.vsr_stats_get(self._h, C.byref(st)))
-        return {f: getattr(st, f) for f, _ in st._fields_}
+        out = {}
+        for f, _ in st._fields_:
+            v = getattr(st, f)
+            out[f] = list(v) if hasattr(v, "__len__") else v
+        return out
 
     def stats_reset(self):
         check(self._lib.vsr_stats_reset(self._h))

@@ -1,0 +1,96 @@
+"""Multi-GPU filtered k-NN: one process per GPU, corpus sharded by contiguous row range.
+
+The reference has no distributed runtime; its only "sharding" is table-per-role / table-per-partition with a
+client-side merge of the partial results (controller/dynamic_partition/search.py:347-364,
+controller/baseline/prefilter/prefilter_role.py:174-189).  Here every rank owns rows [lo, hi) of the
+(document_id, block_id)-ordered corpus, searches them with the same K1/K5 kernels, and the per-rank top-k lists
+(k * 24 bytes per query) are exchanged with ONE all-gather per query batch over RCCL/xGMI and merged on the GPU
+(vsr_merge_topk_device).  Ordering keys carry the global row, so the merged order equals the single-GPU order.
+
+`ShardedSearcher` holds the rank arithmetic and the collective plumbing; the per-shard compute is an `engine`
+object (GpuShardEngine in production).  Tests drive the same class under gloo with a CPU stand-in engine.
+"""
+import ctypes
+
+import numpy as np
+
+
+def shard_bounds(n_rows, world, rank, align=1):
+    """Rows [lo, hi) of rank `rank`; boundaries rounded down to `align` rows so documents stay whole."""
+    def cut(r):
+        if r >= world:
+            return n_rows
+        b = r * n_rows // world
+        return b - b % align
+    return cut(rank), cut(rank + 1)
+
+
+def monotone_keys(rank_values, global_rows):
+    """The library's ordering key: (monotone fp32 bits << 32) | global row.  NaN sorts last, -0 == +0."""
+    v = np.asarray(rank_values, dtype=np.float32) + np.float32(0.0)
+    u = v.view(np.uint32).astype(np.uint64)
+    u = np.where(np.isnan(v), np.uint64(0x7FC00000), u)
+    neg = (u & np.uint64(0x80000000)) != 0
+    m = np.where(neg, (~u) & np.uint64(0xFFFFFFFF), u | np.uint64(0x80000000))
+    return (m << np.uint64(32)) | np.asarray(global_rows, dtype=np.uint64)
+
+
+class ShardedSearcher:
+    def __init__(self, engine, world=1, rank=0, dist=None, group=None):
+        self.engine, self.world, self.rank, self.dist, self.group = engine, world, rank, dist, group
+
+    def search(self, queries, k, metric="l2", filters=None):
+        """Every rank passes the same queries; returns (block_ids, doc_ids, dist, counts) of the global top-k."""
+        local = self.engine.search_local(queries, k, metric, filters)      # dict of [nq, k] tensors
+        if self.world == 1:
+            return self.engine.finalize(local)
+        import torch
+        gathered = {}
+        for name in ("keys", "block", "doc", "dist"):
+            t = local[name].contiguous()
+            g = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(g, t, group=self.group)       # concatenation along dim 0
+            gathered[name] = g.view((self.world,) + tuple(t.shape))
+        return self.engine.merge(gathered, k)
+
+
+class GpuShardEngine:
+    """Per-shard compute on one MI355X through the C ABI (device pointers; torch only owns the buffers)."""
+
+    def __init__(self, ctx, corpus, device):
+        import torch
+        self.torch, self.ctx, self.corpus, self.device = torch, ctx, corpus, device
+        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def search_local(self, queries, k, metric, filters):
+        torch = self.torch
+        q = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries, np.float32))
+        q = q.to(self.device, torch.float32).contiguous()
+        nq = q.shape[0]
+        out = {"block": torch.empty((nq, k), dtype=torch.int64, device=self.device),
+               "doc": torch.empty((nq, k), dtype=torch.int32, device=self.device),
+               "dist": torch.empty((nq, k), dtype=torch.float32, device=self.device),
+               "keys": torch.empty((nq, k), dtype=torch.int64, device=self.device),
+               "counts": torch.empty((nq,), dtype=torch.int32, device=self.device)}
+        self._keep = self.corpus.search_device(self._p(q), nq, k, metric, filters, self._p(out["block"]),
+                                               self._p(out["doc"]), None, self._p(out["dist"]),
+                                               self._p(out["counts"]), self._p(out["keys"]))
+        return out
+
+    def finalize(self, local):
+        return local["block"], local["doc"], local["dist"], local["counts"]
+
+    def merge(self, g, k):
+        torch = self.torch
+        world, nq = g["keys"].shape[0], g["keys"].shape[1]
+        blk = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        doc = torch.empty((nq, k), dtype=torch.int32, device=self.device)
+        dist = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        cnt = torch.empty((nq,), dtype=torch.int32, device=self.device)
+        self.ctx.merge_topk_device(self._p(g["keys"]), self._p(g["block"]), self._p(g["doc"]), self._p(g["dist"]),
+                                   world, nq, k, self._p(blk), self._p(doc), self._p(dist), None, self._p(cnt))
+        return blk, doc, dist, cnt
