@@ -10,6 +10,13 @@ for p in (ROOT, os.path.join(ROOT, "vectorsearch-rbac_amd")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# PyTorch wheels bundle their own HIP runtime; when torch and libvsrbac share a process torch must load first so
+# that both bind the same libamdhip64 ("Sharing a process with PyTorch").
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

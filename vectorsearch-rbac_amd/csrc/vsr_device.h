@@ -9,8 +9,12 @@ constexpr uint64_t KEY_EMPTY = ~0ull;     // sorts after every real key (NaN key
 constexpr int      SCAN_THREADS = 512;    // 8 waves per workgroup
 constexpr int      SCAN_WAVES = SCAN_THREADS / 64;
 constexpr int      SELECT_THREADS = 1024;
-constexpr int      APPEND_SLACK = 512;    // max keys appended between two overflow checks
 constexpr int      MAX_K = 2048;
+constexpr int      SCAN_QMAX = 16;        // most queries that can share one corpus pass
+constexpr size_t   SCAN_LDS_BUDGET = 72 * 1024;   // per workgroup, so two workgroups fit a CU's 160 KiB
+
+// keys one workgroup may append per query between two overflow checks (tile rows x waves, >= 256)
+constexpr int scan_slack(int rw) { return SCAN_WAVES * rw > 256 ? SCAN_WAVES * rw : 256; }
 
 enum Metric : int { M_L2 = 0, M_IP = 1, M_COSINE = 2, M_L1 = 3 };
 
@@ -39,6 +43,7 @@ struct ScanParams {
     uint32_t         kp;           // partial list length (>= k)
     uint32_t         k;
     uint32_t         cap;          // LDS candidate capacity per query (power of two)
+    uint32_t         qmax;         // query slots per workgroup (multiple of the kernel's QI)
 };
 
 // Per query: which partial lists to merge and where to put the result.
@@ -46,11 +51,11 @@ struct SelectQuery {
     uint32_t partial_begin;
     uint32_t n_lists;              // lists are partial_begin + j, j < n_lists
     uint32_t out_slot;             // output row in the result arrays (caller's query index)
-    uint32_t pad;
+    uint32_t dst_list;             // 0xFFFFFFFF: write final results; else: write the k best keys as partial list dst_list
 };
 
 struct SelectParams {
-    const uint64_t*    partial;
+    uint64_t*          partial;
     const SelectQuery* queries;
     uint32_t           kp;
     uint32_t           k;
@@ -79,8 +84,13 @@ struct KernelShape {
 
 // host-side launchers (vsr_kernels.hip)
 KernelShape scan_shape_for_dim(int dim);
-int  scan_max_qb(int dim, int k);
-hipError_t launch_scan(const ScanParams& p, int metric, int dim, int qb, uint32_t n_blocks, hipStream_t s);
+uint32_t scan_cap_for_k(int k, int dim);
+int  scan_qmax(int dim, int k);    // queries per pass the LDS budget allows (1, or a multiple of 4 up to SCAN_QMAX)
+inline size_t scan_lds_bytes(uint32_t qmax, uint32_t cap, uint32_t stride4)
+{
+    return (size_t) qmax * ((size_t) cap * 8 + 16 + (size_t) stride4 * 16 + 4) + 16;
+}
+hipError_t launch_scan(const ScanParams& p, int metric, int dim, int qi, uint32_t n_blocks, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);
 hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,
@@ -95,6 +105,5 @@ hipError_t launch_merge_lists(const uint64_t* keys, const int64_t* blocks, const
                               hipStream_t s);
 hipError_t launch_gather_queries(const float* src, const uint32_t* slot_query, uint32_t nq, uint32_t dim,
                                  uint32_t qfloats, float* dst, hipStream_t s);
-uint32_t cap_for_k(int k);
 
 }  // namespace vsr

@@ -24,28 +24,34 @@ KernelShape scan_shape_for_dim(int dim)
     return {64, 0, 2, 2};
 }
 
-uint32_t cap_for_k(int k)
+uint32_t scan_cap_for_k(int k, int dim)
 {
-    // room for k kept keys + APPEND_SLACK new ones, with a trigger level >= 2k so compactions amortise
-    uint32_t cap = 1024;
-    while (cap < (uint32_t) (2 * k + APPEND_SLACK)) cap <<= 1;
+    // room for k kept keys plus one check interval of new ones, trigger level >= 2k so compactions amortise
+    const int slack = scan_slack(scan_shape_for_dim(dim).rw);
+    uint32_t cap = 512;
+    while (cap < (uint32_t) (2 * k + slack)) cap <<= 1;
     return cap;
 }
 
-int scan_max_qb(int dim, int k)
+int scan_qmax(int dim, int k)
 {
     const KernelShape sh = scan_shape_for_dim(dim);
-    if (sh.c == 0) return 1;
-    return (size_t) 4 * cap_for_k(k) * sizeof(uint64_t) <= 64 * 1024 ? 4 : 1;
+    const uint32_t stride4 = (uint32_t) ((dim + 3) / 4);
+    const size_t per_query = scan_lds_bytes(1, scan_cap_for_k(k, dim), stride4) - 16;
+    int q = (int) (SCAN_LDS_BUDGET / per_query);
+    if (sh.c == 0) q = q < 4 ? q : 4;            // runtime-chunk kernel: one sub-batch only
+    if (q >= 4) q = (q < SCAN_QMAX ? q : SCAN_QMAX) / 4 * 4;
+    else q = 1;
+    return q;
 }
 
-hipError_t launch_scan(const ScanParams& p, int metric, int dim, int qb, uint32_t n_blocks, hipStream_t s)
+hipError_t launch_scan(const ScanParams& p, int metric, int dim, int qi, uint32_t n_blocks, hipStream_t s)
 {
     switch (metric) {
-    case M_L2:     return launch_scan_l2(p, dim, qb, n_blocks, s);
-    case M_IP:     return launch_scan_ip(p, dim, qb, n_blocks, s);
-    case M_COSINE: return launch_scan_cosine(p, dim, qb, n_blocks, s);
-    case M_L1:     return launch_scan_l1(p, dim, qb, n_blocks, s);
+    case M_L2:     return launch_scan_l2(p, dim, qi, n_blocks, s);
+    case M_IP:     return launch_scan_ip(p, dim, qi, n_blocks, s);
+    case M_COSINE: return launch_scan_cosine(p, dim, qi, n_blocks, s);
+    case M_L1:     return launch_scan_l1(p, dim, qi, n_blocks, s);
     default:       return hipErrorInvalidValue;
     }
 }
@@ -78,17 +84,28 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(const SelectPara
     const uint64_t* src = p.partial + (size_t) sq.partial_begin * p.kp;
     const uint64_t total = (uint64_t) sq.n_lists * p.kp;
     const uint32_t trigger = cap - SELECT_THREADS;
+    uint64_t next = (uint64_t) tid < total ? src[tid] : KEY_EMPTY;            // one key ahead of the loop
     for (uint64_t base = 0; base < total; base += SELECT_THREADS) {
-        const uint64_t i = base + tid;
-        const uint64_t key = i < total ? src[i] : KEY_EMPTY;
+        const uint64_t key = next;
+        const uint64_t in = base + SELECT_THREADS + tid;
+        next = in < total ? src[in] : KEY_EMPTY;
         const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl->tau);
         topk_append(keys, ctrl, key < tau, key);            // KEY_EMPTY never passes (tau <= KEY_EMPTY)
-        const bool need = *reinterpret_cast<volatile uint32_t*>(&ctrl->count) > trigger;
-        if (base + SELECT_THREADS < total && __syncthreads_or(need))
-            topk_compact<SELECT_THREADS>(keys, ctrl, k, tid, false);
+        if (base + SELECT_THREADS < total) {
+            __syncthreads();                                 // every append of this round is counted
+            if (ctrl->count > trigger) topk_compact<SELECT_THREADS>(keys, ctrl, k, tid, false);
+            else __syncthreads();                            // nobody appends before all have read count
+        }
     }
     __syncthreads();
     topk_compact<SELECT_THREADS>(keys, ctrl, k, tid, true);
+
+    if (sq.dst_list != 0xFFFFFFFFu) {                        // level 1 of a two-level merge
+        const uint32_t n = ctrl->count < k ? ctrl->count : k;
+        uint64_t* dst = p.partial + (size_t) sq.dst_list * p.kp;
+        for (uint32_t i = tid; i < p.kp; i += SELECT_THREADS) dst[i] = i < n ? keys[i] : KEY_EMPTY;
+        return;
+    }
 
     const uint32_t m = ctrl->count < k ? ctrl->count : k;
     const size_t out = (size_t) sq.out_slot * k;

@@ -120,7 +120,7 @@ struct vsr_ctx {
     // knobs
     int block_budget = 0;          // 0 = 4 * CUs
     int min_rows_per_block = 256;
-    int max_qb = 4;
+    int max_qb = SCAN_QMAX;
 };
 
 struct vsr_filter {
@@ -505,6 +505,25 @@ static int upload_tiles(vsr_filter* f, const std::vector<uint2>& tiles)
     return VSR_OK;
 }
 
+// contiguous permitted row ranges -> the RW-aligned row windows that hold at least one permitted row
+// (bitmap mode: the per-row bits decide inside each window; windows without a set bit are never visited)
+static int64_t ranges_to_aligned_tiles(const std::vector<std::pair<uint32_t, uint32_t>>& ranges, int rw, int64_t n,
+                                       std::vector<uint2>& tiles)
+{
+    int64_t rows = 0;
+    int64_t last = -1;
+    for (auto& r : ranges)
+        for (int64_t t = r.first / rw; t <= (int64_t) (r.second - 1) / rw; ++t) {
+            if (t == last) continue;
+            last = t;
+            const uint32_t s = (uint32_t) (t * rw);
+            const uint32_t cnt = (uint32_t) std::min<int64_t>(rw, n - (int64_t) s);
+            tiles.push_back(make_uint2(s, cnt));
+            rows += cnt;
+        }
+    return rows;
+}
+
 // contiguous permitted row ranges -> tiles of <= RW rows
 static void ranges_to_tiles(const std::vector<std::pair<uint32_t, uint32_t>>& ranges, int rw, std::vector<uint2>& tiles)
 {
@@ -583,8 +602,10 @@ static int build_role_filter(vsr_corpus* c, const std::vector<int32_t>& roles, i
         HIPCHK(launch_build_bitmap(c->d_row_docidx, (uint32_t) c->n, c->d_doc_mask, c->words,
                                    ctx->d_misc.as<uint64_t>(), f->d_bitmap, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));      // m is a stack-owned host buffer
-        f->n_tiles = (uint32_t) ((c->n + c->shape.rw - 1) / c->shape.rw);
-        f->scanned_rows = c->n;
+        std::vector<uint2> tiles;
+        f->scanned_rows = ranges_to_aligned_tiles(ranges, c->shape.rw, c->n, tiles);
+        rc = upload_tiles(f.get(), tiles);
+        if (rc) return rc;
     }
     *out = f.release();
     return VSR_OK;
@@ -637,13 +658,13 @@ extern "C" int vsr_filter_from_bytemask(vsr_corpus* c, const uint8_t* allowed, i
     int64_t cnt = 0;
     for (int64_t i = 0; i < c->n; ++i) cnt += allowed[i] != 0;
     f->allowed_rows = cnt;
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    for (int64_t i = 0; i < c->n; ++i) {
+        if (!allowed[c->h_orig[(size_t) i]]) continue;
+        if (!ranges.empty() && ranges.back().second == (uint32_t) i) ranges.back().second++;
+        else ranges.emplace_back((uint32_t) i, (uint32_t) i + 1);
+    }
     if (mode == VSR_FILTER_RANGES) {
-        std::vector<std::pair<uint32_t, uint32_t>> ranges;
-        for (int64_t i = 0; i < c->n; ++i) {
-            if (!allowed[c->h_orig[(size_t) i]]) continue;
-            if (!ranges.empty() && ranges.back().second == (uint32_t) i) ranges.back().second++;
-            else ranges.emplace_back((uint32_t) i, (uint32_t) i + 1);
-        }
         std::vector<uint2> tiles;
         ranges_to_tiles(ranges, c->shape.rw, tiles);
         int rc = upload_tiles(f.get(), tiles);
@@ -660,8 +681,10 @@ extern "C" int vsr_filter_from_bytemask(vsr_corpus* c, const uint8_t* allowed, i
             HIPCHK(launch_pack_bytemask(ctx->d_misc.as<uint8_t>(), c->d_orig, (uint32_t) c->n, f->d_bitmap, ctx->stream));
         }
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        f->n_tiles = (uint32_t) ((c->n + c->shape.rw - 1) / c->shape.rw);
-        f->scanned_rows = c->n;
+        std::vector<uint2> tiles;
+        f->scanned_rows = ranges_to_aligned_tiles(ranges, c->shape.rw, c->n, tiles);
+        rc = upload_tiles(f.get(), tiles);
+        if (rc) return rc;
     }
     *out = f.release();
     return VSR_OK;
@@ -733,14 +756,20 @@ extern "C" int64_t vsr_filter_scanned_rows(const vsr_filter* f) { return f ? f->
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+constexpr uint32_t SEL_FANIN = 64;           // partial lists one K5 workgroup merges; more -> two levels
+constexpr uint32_t SEL_FINAL = 0xFFFFFFFFu;
+
 struct Plan {
     std::vector<uint32_t>    slot_query;     // slot -> caller query index
-    std::vector<ScanGroup>   groups_qb[2];   // [0]: QB = 1 launch, [1]: QB = max_qb launch
-    uint32_t                 blocks_qb[2] = {0, 0};
-    std::vector<SelectQuery> selq;           // one per query (slot order)
-    uint32_t                 n_partial = 0;
-    int64_t                  scan_rows[2] = {0, 0};
-    int64_t                  scan_bytes[2] = {0, 0};
+    std::vector<ScanGroup>   groups;         // one K1 launch
+    uint32_t                 n_blocks = 0;
+    int                      qi = 1;         // kernel sub-batch width (1 or 4)
+    uint32_t                 qmax = 1;       // query slots per workgroup
+    std::vector<SelectQuery> sel1;           // level-1 K5 items (only for queries with many partial lists)
+    std::vector<SelectQuery> selq;           // final K5 item per query (slot order)
+    uint32_t                 n_partial = 0;  // K1 partial lists + level-1 K5 outputs
+    int64_t                  scan_rows = 0;
+    int64_t                  scan_bytes = 0;
 };
 
 struct PassDesc {
@@ -762,14 +791,16 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fof(a) < fof(b); });
     plan.slot_query = order;
 
-    const int max_qb = std::min(ctx->max_qb, scan_max_qb(c->dim, k)) >= 4 ? 4 : 1;
+    int qmax = std::min(ctx->max_qb, scan_qmax(c->dim, k));
+    qmax = qmax >= 4 ? qmax / 4 * 4 : 1;
     std::vector<PassDesc> passes;
+    uint32_t widest = 1;
     for (uint32_t s = 0; s < (uint32_t) nq;) {
         const vsr_filter* f = fof(order[s]);
         uint32_t e = s;
         while (e < (uint32_t) nq && fof(order[e]) == f) ++e;
         for (uint32_t b = s; b < e;) {
-            const uint32_t cnt = std::min<uint32_t>(e - b, (uint32_t) max_qb);
+            const uint32_t cnt = std::min<uint32_t>(e - b, (uint32_t) qmax);
             PassDesc pd;
             pd.f = f;
             pd.q_begin = b;
@@ -777,20 +808,22 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
             pd.rows = f ? f->scanned_rows : c->n;
             pd.n_tiles = f ? f->n_tiles : (uint32_t) ((c->n + c->shape.rw - 1) / c->shape.rw);
             passes.push_back(pd);
+            widest = std::max(widest, cnt);
             b += cnt;
         }
         s = e;
     }
+    // one launch: the 4-wide kernel as soon as any pass carries more than one query
+    plan.qi = widest > 1 ? 4 : 1;
+    plan.qmax = plan.qi == 1 ? 1 : (widest + 3) / 4 * 4;
 
-    // the two kernel classes run back to back on the stream: each launch gets the whole block budget
-    int64_t total_rows[2] = {0, 0};
-    for (auto& p : passes) total_rows[p.q_count > 1 ? 1 : 0] += std::max<int64_t>(p.rows, 1);
+    int64_t total_rows = 0;
+    for (auto& p : passes) total_rows += std::max<int64_t>(p.rows, 1);
     const int64_t budget = ctx->block_budget > 0 ? ctx->block_budget : 4 * (int64_t) ctx->prop.multiProcessorCount;
 
     plan.selq.resize((size_t) nq);
     for (auto& p : passes) {
-        const int li = p.q_count > 1 ? 1 : 0;
-        int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows[li] - 1) / total_rows[li];
+        int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows - 1) / total_rows;
         nb = std::min<int64_t>(nb, std::max<int64_t>(1, p.rows / ctx->min_rows_per_block));
         nb = std::min<int64_t>(nb, std::max<uint32_t>(1, p.n_tiles));
         nb = std::max<int64_t>(nb, 1);
@@ -800,24 +833,40 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
             sq.partial_begin = plan.n_partial + qi * (uint32_t) nb;
             sq.n_lists = empty ? 0 : (uint32_t) nb;
             sq.out_slot = order[p.q_begin + qi];
-            sq.pad = 0;
+            sq.dst_list = SEL_FINAL;
             plan.selq[p.q_begin + qi] = sq;
         }
         if (empty) continue;
         ScanGroup g;
-        g.tiles = p.f && p.f->mode == VSR_FILTER_RANGES ? p.f->d_tiles : nullptr;
+        g.tiles = p.f ? p.f->d_tiles : nullptr;
         g.bitmap = p.f ? p.f->d_bitmap : nullptr;
         g.n_tiles = p.n_tiles;
         g.q_begin = p.q_begin;
         g.q_count = p.q_count;
-        g.block_begin = plan.blocks_qb[li];
+        g.block_begin = plan.n_blocks;
         g.n_blocks = (uint32_t) nb;
         g.partial_begin = plan.n_partial;
-        plan.groups_qb[li].push_back(g);
-        plan.blocks_qb[li] += (uint32_t) nb;
+        plan.groups.push_back(g);
+        plan.n_blocks += (uint32_t) nb;
         plan.n_partial += (uint32_t) nb * p.q_count;
-        plan.scan_rows[li] += p.rows;
-        plan.scan_bytes[li] += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12;
+        plan.scan_rows += p.rows;
+        plan.scan_bytes += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12;
+    }
+    // queries with many partial lists get a first K5 level of SEL_FANIN-list merges
+    for (auto& sq : plan.selq) {
+        if (sq.n_lists <= SEL_FANIN) continue;
+        const uint32_t n1 = (sq.n_lists + SEL_FANIN - 1) / SEL_FANIN;
+        for (uint32_t j = 0; j < n1; ++j) {
+            SelectQuery s1;
+            s1.partial_begin = sq.partial_begin + j * SEL_FANIN;
+            s1.n_lists = std::min<uint32_t>(SEL_FANIN, sq.n_lists - j * SEL_FANIN);
+            s1.out_slot = 0;
+            s1.dst_list = plan.n_partial + j;
+            plan.sel1.push_back(s1);
+        }
+        sq.partial_begin = plan.n_partial;
+        sq.n_lists = n1;
+        plan.n_partial += n1;
     }
 }
 
@@ -834,12 +883,12 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
 
     const uint32_t kp = (uint32_t) k;
     const size_t qfloats = (size_t) c->stride4 * 4;
-    // one staging block: [queries | q_norm2 | groups(QB=1) | groups(QB=4) | select queries]
+    // one staging block: [queries | q_norm2 | scan groups | level-1 select | final select | slot map]
     const size_t off_q = 0;
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
-    const size_t off_g0 = align_up(off_qn + (size_t) nq * sizeof(float), 256);
-    const size_t off_g1 = align_up(off_g0 + plan.groups_qb[0].size() * sizeof(ScanGroup), 256);
-    const size_t off_sq = align_up(off_g1 + plan.groups_qb[1].size() * sizeof(ScanGroup), 256);
+    const size_t off_g = align_up(off_qn + (size_t) nq * sizeof(float), 256);
+    const size_t off_s1 = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
+    const size_t off_sq = align_up(off_s1 + plan.sel1.size() * sizeof(SelectQuery), 256);
     const size_t off_sl = align_up(off_sq + plan.selq.size() * sizeof(SelectQuery), 256);
     const size_t total = align_up(off_sl + (size_t) nq * sizeof(uint32_t), 256);
 
@@ -854,7 +903,6 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     char* hs = ctx->h_desc.as<char>();
     char* ds = ctx->d_desc.as<char>();
     float* hq = reinterpret_cast<float*>(hs + off_q);
-    float* hqn = reinterpret_cast<float*>(hs + off_qn);
     if (h_queries) {
         for (int s = 0; s < nq; ++s) {
             const float* src = h_queries + (size_t) plan.slot_query[(size_t) s] * dim;
@@ -863,21 +911,20 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
             for (size_t j = (size_t) dim; j < qfloats; ++j) dst[j] = 0.0f;
         }
     }
-    memcpy(hs + off_g0, plan.groups_qb[0].data(), plan.groups_qb[0].size() * sizeof(ScanGroup));
-    memcpy(hs + off_g1, plan.groups_qb[1].data(), plan.groups_qb[1].size() * sizeof(ScanGroup));
+    memcpy(hs + off_g, plan.groups.data(), plan.groups.size() * sizeof(ScanGroup));
+    memcpy(hs + off_s1, plan.sel1.data(), plan.sel1.size() * sizeof(SelectQuery));
     memcpy(hs + off_sq, plan.selq.data(), plan.selq.size() * sizeof(SelectQuery));
     memcpy(hs + off_sl, plan.slot_query.data(), (size_t) nq * sizeof(uint32_t));
     if (h_queries) {
         HIPCHK(hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream));
     } else {
-        HIPCHK(hipMemcpyAsync(ds + off_g0, hs + off_g0, total - off_g0, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ds + off_g, hs + off_g, total - off_g, hipMemcpyHostToDevice, ctx->stream));
         // gather the caller's device queries into padded slot order
         HIPCHK(launch_gather_queries(d_queries, reinterpret_cast<const uint32_t*>(ds + off_sl), (uint32_t) nq, (uint32_t) dim,
                                      (uint32_t) qfloats, reinterpret_cast<float*>(ds + off_q), ctx->stream));
     }
     HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
     ctx->desc_pending = true;
-    (void) hqn;
 
     ScanParams sp;
     sp.rows = c->d_rows;
@@ -889,33 +936,33 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sp.partial = ctx->d_partial.as<uint64_t>();
     sp.kp = kp;
     sp.k = (uint32_t) k;
-    sp.cap = cap_for_k(k);
+    sp.cap = scan_cap_for_k(k, c->dim);
+    sp.qmax = plan.qmax;
+    sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
+    sp.n_groups = (uint32_t) plan.groups.size();
     if (metric == VSR_METRIC_COSINE)   // |q|^2 with the same kernel that made the row norms
         HIPCHK(launch_row_norms(reinterpret_cast<const float4*>(sp.queries), (uint32_t) nq, c->stride4,
                                 reinterpret_cast<float*>(ds + off_qn), ctx->stream));
 
-    for (int li = 0; li < 2; ++li) {
-        if (!plan.blocks_qb[li]) continue;
-        sp.groups = reinterpret_cast<const ScanGroup*>(ds + (li ? off_g1 : off_g0));
-        sp.n_groups = (uint32_t) plan.groups_qb[li].size();
+    const int cls = plan.qi == 4 ? 1 : 0;
+    if (plan.n_blocks) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->profiling) {
             e0 = take_event(ctx);
             e1 = take_event(ctx);
             HIPCHK(hipEventRecord(e0, ctx->stream));
         }
-        HIPCHK(launch_scan(sp, metric, c->dim, li ? 4 : 1, plan.blocks_qb[li], ctx->stream));
+        HIPCHK(launch_scan(sp, metric, c->dim, plan.qi, plan.n_blocks, ctx->stream));
         if (e0) {
             HIPCHK(hipEventRecord(e1, ctx->stream));
-            ctx->pending.push_back({e0, e1, li});
+            ctx->pending.push_back({e0, e1, cls});
         }
-        ctx->stats.scan_bytes[li] += plan.scan_bytes[li];
-        ctx->stats.scan_rows[li] += plan.scan_rows[li];
+        ctx->stats.scan_bytes[cls] += plan.scan_bytes;
+        ctx->stats.scan_rows[cls] += plan.scan_rows;
     }
 
     SelectParams sel;
     sel.partial = ctx->d_partial.as<uint64_t>();
-    sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
     sel.kp = kp;
     sel.k = (uint32_t) k;
     sel.cap = 2048;
@@ -937,6 +984,11 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
         s1 = take_event(ctx);
         HIPCHK(hipEventRecord(s0, ctx->stream));
     }
+    if (!plan.sel1.empty()) {
+        sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_s1);
+        HIPCHK(launch_select(sel, (uint32_t) plan.sel1.size(), ctx->stream));
+    }
+    sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
     HIPCHK(launch_select(sel, (uint32_t) nq, ctx->stream));
     if (s0) {
         HIPCHK(hipEventRecord(s1, ctx->stream));
