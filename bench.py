@@ -43,7 +43,10 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--queries", type=int, default=1000, help="queries per step")
     ap.add_argument("--mode", choices=["prefilter", "postfilter"], default="prefilter")
-    ap.add_argument("--cpu-queries", type=int, default=192, help="sample size of the CPU baseline leg")
+    ap.add_argument("--cpu-queries", type=int, default=1000, help="sample size of the CPU baseline leg")
+    ap.add_argument("--cpu-reps", type=int, default=2, help="repetitions of the CPU sample (10-30 s of CPU work)")
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r1", "traffic.json"),
+                    help="PMC-derived HBM bytes per launch (tools/pmc_traffic.py) for roofline.traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20251121)
     return ap.parse_args()
@@ -134,6 +137,7 @@ def main():
     dt = time.perf_counter() - t1
     st = ctx.stats()
     ctx.profiling(False)
+    flagged_total, _ = ctx.screening_check(0)         # K2 / seeding exactness flags over the whole run (expect 0)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -148,12 +152,27 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": f"vsr::scan_kernel<L2, LPR=32, C=1, R=8, QB={4 if cls else 1}>",
+        "kernel": "vsr::mfma_scan_kernel<L2, 2, false> (K2 main pass)" if cls else
+                  "vsr::scan_kernel<L2, LPR=32, C=1, R=8, QI=1>",
         "launch_ms": round(ms_avg, 4), "bytes_per_launch": int(bytes_per_launch),
         "launches": int(launches),
         "all_scan_ms": [round(v, 3) for v in st["scan_ms"]], "all_scan_bytes": [int(v) for v in st["scan_bytes"]],
         "select_ms": round(st["select_ms"], 3),
     }
+
+    workload_tag = f"{n}x{dim} k={k} q={nq} {args.mode} gpus={world}"
+    try:      # HBM bytes per launch from a PMC pass of this same command (never measured inside the timed run)
+        with open(args.traffic) as f:
+            tr = json.load(f)
+        if tr.get("workload") == workload_tag:
+            for name, v in tr["kernels"].items():
+                main = ("mfma_scan_kernel" in name and "false>" in name) if cls else ("vsr::scan_kernel" in name)
+                if main:
+                    roofline["traffic"] = int(v["hbm_bytes_per_launch"])
+                    roofline["traffic_source"] = os.path.relpath(args.traffic, ROOT) + ": " + tr["method"]
+    except (OSError, ValueError, KeyError):
+        pass
+    roofline["workload_tag"] = workload_tag
 
     out = {
         "metric": "QPS at recall@100, SIFT10M filtered-kNN (role RBAC), 1/2/4/8 MI355X",
@@ -167,6 +186,7 @@ def main():
                    "sharding": f"row-range x{world}", "recall": 1.0},
         "roofline": roofline,
         "setup_s": {"generate": round(t_gen, 1), "load": round(t_load, 1)},
+        "screening_flagged_queries": int(flagged_total),
     }
 
     # ---- CPU baseline (rank 0, N = 1): the oracle, pgvector's flags, one thread, bounded sample ----
@@ -179,15 +199,17 @@ def main():
             docs = rbac.visible_docs(int(u)).astype(np.int64)
             ranges.append([((d - 1) * 100, 100) for d in docs])
         tc = time.perf_counter()
-        rows_o, dist_o, cnt_o = orc.search_ranges("l2", x, qvec[:m], k, ranges, doc, blk)
-        cpu_s = time.perf_counter() - tc
+        for _ in range(max(1, args.cpu_reps)):
+            rows_o, dist_o, cnt_o = orc.search_ranges("l2", x, qvec[:m], k, ranges, doc, blk)
+        cpu_s = (time.perf_counter() - tc) / max(1, args.cpu_reps)
         got_rows = d_row[:m].cpu().numpy()
         got_dist = d_dist[:m].cpu().numpy()
         ok = bool((got_rows == rows_o).all() and (got_dist == dist_o.astype(np.float32)).all())
         out["cpu_baseline"] = {
             "value": round(m / cpu_s, 2), "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"first {m} queries of the step, exact seq-scan of each user's role partition, "
-                      f"{cpu_s:.1f} s on 1 of {os.cpu_count()} host cores (oracle built with pgvector's flags)",
+            "sample": f"first {m} queries of the step x {max(1, args.cpu_reps)} repetitions, exact seq-scan of each "
+                      f"user's role partition, {cpu_s * max(1, args.cpu_reps):.1f} s on 1 of {os.cpu_count()} host "
+                      f"cores (oracle built with pgvector's flags)",
         }
         out["parity_spot_check"] = {"queries": int(m), "ids_and_distances_identical": ok}
     if rank == 0:

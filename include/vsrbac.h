@@ -134,6 +134,14 @@ int vsr_search_device(vsr_corpus* corpus, const float* d_queries, int nq, int di
                       int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows,
                       float* d_out_dist, int32_t* d_out_counts, uint64_t* d_out_keys);
 
+/* Shared passes of L2 / inner-product / cosine searches may run on the matrix cores: an fp32-MFMA screening keeps
+ * 2k candidates per query and an exact re-rank reports the k best.  The re-rank flags a
+ * query when the screening's rounding error could have excluded a true result; vsr_search re-runs flagged queries on
+ * the exact path itself.  After vsr_search_device the caller checks: flagged_total = flagged queries since vsr_open,
+ * flags_last_call[i] != 0 = query i of the last call must be re-run with screening disabled.  Synchronises. */
+int vsr_set_screening(vsr_ctx* ctx, int enable);           /* default: enabled */
+int vsr_screening_check(vsr_ctx* ctx, int64_t* flagged_total, int32_t* flags_last_call, int nq);
+
 /* merge n_parts per-shard results (layout [n_parts][nq][k], as all-gathered from vsr_search_device) into the
  * global top-k: the client-side merge of search.py:347-364 done on the GPU. */
 int vsr_merge_topk_device(vsr_ctx* ctx, const uint64_t* d_keys, const int64_t* d_block_ids,

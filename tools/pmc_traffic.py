@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` into profiles/<round>/traffic.json.
+
+Per MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB (hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024);
+on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so the
+read side is doubled; WRITE_SIZE is exact.  The two counters need separate passes (TCC slots).
+
+  python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> [workload-tag]
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    files = glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
+    agg = defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    tag = sys.argv[4] if len(sys.argv) > 4 else ""
+    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
+    write = per_kernel(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for name in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(name, (0.0, 0))
+        w, nw = write.get(name, (0.0, 0))
+        kernels[name] = {
+            "fetch_size_kib_avg": f, "write_size_kib_avg": w, "dispatches": max(nf, nw),
+            "hbm_read_bytes_per_launch": f * 1024 * 2,      # gfx950: FETCH_SIZE = 1/2 of wide streaming reads
+            "hbm_write_bytes_per_launch": w * 1024,
+            "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
+        }
+    json.dump({"workload": tag, "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
+               "KiB units, FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)", "kernels": kernels},
+              open(out, "w"), indent=1)
+    for k, v in kernels.items():
+        print(f"{v['hbm_bytes_per_launch'] / 1e9:10.3f} GB/launch  x{v['dispatches']:<4d} {k[:90]}")
+
+
+if __name__ == "__main__":
+    main()

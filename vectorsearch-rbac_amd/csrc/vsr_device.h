@@ -44,6 +44,12 @@ struct ScanParams {
     uint32_t         k;
     uint32_t         cap;          // LDS candidate capacity per query (power of two)
     uint32_t         qmax;         // query slots per workgroup (multiple of the kernel's QI)
+    uint64_t*        cand;         // K1m only: [n_partial][cap] candidate buffers in global memory
+    uint32_t         rw;           // rows per list tile (the corpus shape's RW)
+    const uint64_t*  tau_init;     // [n_slots] seeded thresholds (sample pass), nullptr = none
+    uint32_t         sample_stride;  // 1 = every tile; S > 1 = sample pass over every S-th tile of each workgroup
+    uint32_t         debug;        // measurement only: bit 0 = never append candidates (isolates the streaming/compute part)
+    unsigned long long* dbg;       // measurement only (VSR_DEBUG bit 1): [0] compactions, [1] appended keys, [2] tiles
 };
 
 // Per query: which partial lists to merge and where to put the result.
@@ -51,10 +57,20 @@ struct SelectQuery {
     uint32_t partial_begin;
     uint32_t n_lists;              // lists are partial_begin + j, j < n_lists
     uint32_t out_slot;             // output row in the result arrays (caller's query index)
-    uint32_t dst_list;             // 0xFFFFFFFF: write final results; else: write the k best keys as partial list dst_list
+    uint32_t dst_list;             // SEL_FINAL: write final results; SEL_SEED: write the seed threshold;
+                                   // else: write the k best keys as partial list dst_list
+    uint32_t allowed;              // rows the query's filter admits (saturated): completeness check of seeded runs
+    uint32_t pad;
 };
 
+constexpr uint32_t SEL_FINAL = 0xFFFFFFFFu;
+constexpr uint32_t SEL_SEED = 0xFFFFFFFEu;
+
 struct SelectParams {
+    uint64_t*          tau_out;        // SEL_SEED items: [n_slots] thresholds
+    int32_t*           out_flags;      // final items of seeded runs: 1 = fewer results than the filter admits
+    int32_t*           flagged_total;
+    int                seeded;
     uint64_t*          partial;
     const SelectQuery* queries;
     uint32_t           kp;
@@ -75,6 +91,33 @@ struct SelectParams {
     int32_t*           out_count;
 };
 
+// K5r: exact re-rank of the kp screening survivors of each query (after K2)
+struct RerankParams {
+    const uint64_t*    lists;          // [n_queries][kp] screening keys (ascending, KEY_EMPTY padded), by slot
+    const SelectQuery* queries;        // out_slot per slot
+    const float4*      rows;
+    uint32_t           stride4;
+    const float*       queries_f;      // [n_slots][stride4*4] padded query vectors (slot order)
+    uint32_t           kp, k;
+    int                metric;
+    int                dim;
+    const float*       norm2_max;      // max |row|^2 of the corpus (error bound of the screening)
+    uint32_t           row_offset;
+    const int64_t*     block_ids;
+    const int32_t*     doc_ids;
+    const int64_t*     orig_rows;
+    int64_t*           out_block;
+    int32_t*           out_doc;
+    int64_t*           out_row;
+    float*             out_dist;
+    uint64_t*          out_keys;
+    int32_t*           out_count;
+    int                seeded;         // thresholds were seeded from a sample: also check completeness
+    const uint64_t*    tau_init;       // [n_slots] the seeds (bound on every excluded row when the list is not full)
+    int32_t*           out_flags;      // [n_queries] by out_slot: 1 = screening gap inside the error bound
+    int32_t*           flagged_total;  // running count of flagged queries
+};
+
 struct KernelShape {
     int lpr;     // lanes per row
     int c;       // float4 chunks per lane per row (0 = runtime loop)
@@ -91,6 +134,22 @@ inline size_t scan_lds_bytes(uint32_t qmax, uint32_t cap, uint32_t stride4)
     return (size_t) qmax * ((size_t) cap * 8 + 16 + (size_t) stride4 * 16 + 4) + 16;
 }
 hipError_t launch_scan(const ScanParams& p, int metric, int dim, int qi, uint32_t n_blocks, hipStream_t s);
+// K1m (vsr_mq.h): shared-pass kernel for 2..16 queries per pass; needs dim >= 61 (>= 16 float4 per row)
+bool mq_supported(int dim);
+int  mq_qmax(int dim);
+hipError_t launch_mq(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
+// K2 (vsr_mfma.h): fp32-MFMA screening for shared passes (L2 / IP / cosine), followed by K5r
+hipError_t launch_mfma(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
+inline size_t mfma_lds_bytes(uint32_t stride4)
+{
+    const uint32_t nstage = (stride4 + 15) / 16;
+    return (size_t) 4 * 64 * 16 * 16                       // 4 wave staging images (swizzled, no padding)
+         + (size_t) 4 * 64 * 8                             // row index + |row|^2 per slot
+         + (size_t) 16 * nstage * 16 * 16                  // 16 queries, zero padded to whole stages
+         + (size_t) 16 * 20 + 32;
+}
+hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
+hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);
 hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,

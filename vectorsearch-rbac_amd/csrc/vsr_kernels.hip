@@ -10,6 +10,51 @@ hipError_t launch_scan_ip(const ScanParams&, int, int, uint32_t, hipStream_t);
 hipError_t launch_scan_cosine(const ScanParams&, int, int, uint32_t, hipStream_t);
 hipError_t launch_scan_l1(const ScanParams&, int, int, uint32_t, hipStream_t);
 
+hipError_t launch_mq_l2(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_mq_ip(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_mq_cosine(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_mq_l1(const ScanParams&, uint32_t, hipStream_t);
+
+hipError_t launch_mfma_l2(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_mfma_ip(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_mfma_cosine(const ScanParams&, uint32_t, hipStream_t);
+
+hipError_t launch_mfma(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s)
+{
+    switch (metric) {
+    case M_L2:     return launch_mfma_l2(p, n_blocks, s);
+    case M_IP:     return launch_mfma_ip(p, n_blocks, s);
+    case M_COSINE: return launch_mfma_cosine(p, n_blocks, s);
+    default:       return hipErrorInvalidValue;
+    }
+}
+
+bool mq_supported(int dim) { return (dim + 3) / 4 >= 16; }
+
+int mq_qmax(int dim)
+{
+    // LDS per workgroup = 4 wave staging images (~70 KB) + the queries; prefer two workgroups per CU
+    const size_t stride4 = (size_t) (dim + 3) / 4;
+    const size_t per_query = (stride4 + 15) / 16 * 16 * 16 + 32;
+    const size_t fixed = (size_t) 4 * 64 * 17 * 16 + 4 * 64 * 4 + 64;
+    auto fit = [&](size_t budget) { return budget > fixed ? (int) ((budget - fixed) / per_query) : 0; };
+    int q = fit(80 * 1024);
+    if (q < 8) q = fit(160 * 1024);
+    q = q < SCAN_QMAX ? q : SCAN_QMAX;
+    return q >= 4 ? q / 4 * 4 : 0;
+}
+
+hipError_t launch_mq(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s)
+{
+    switch (metric) {
+    case M_L2:     return launch_mq_l2(p, n_blocks, s);
+    case M_IP:     return launch_mq_ip(p, n_blocks, s);
+    case M_COSINE: return launch_mq_cosine(p, n_blocks, s);
+    case M_L1:     return launch_mq_l1(p, n_blocks, s);
+    default:       return hipErrorInvalidValue;
+    }
+}
+
 KernelShape scan_shape_for_dim(int dim)
 {
     const int d4 = (dim + 3) / 4;
@@ -100,7 +145,13 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(const SelectPara
     __syncthreads();
     topk_compact<SELECT_THREADS>(keys, ctrl, k, tid, true);
 
-    if (sq.dst_list != 0xFFFFFFFFu) {                        // level 1 of a two-level merge
+    if (sq.dst_list == SEL_SEED) {
+        // seed threshold from the sample pass: every row ranking at or before the k-th sampled candidate stays
+        // eligible in the main pass (low word all ones: ties of that distance included); too few samples: no seed
+        if (tid == 0) p.tau_out[sq.out_slot] = ctrl->count >= k ? (keys[k - 1] | 0xFFFFFFFFull) : KEY_EMPTY;
+        return;
+    }
+    if (sq.dst_list != SEL_FINAL) {                          // level 1 of a two-level merge
         const uint32_t n = ctrl->count < k ? ctrl->count : k;
         uint64_t* dst = p.partial + (size_t) sq.dst_list * p.kp;
         for (uint32_t i = tid; i < p.kp; i += SELECT_THREADS) dst[i] = i < n ? keys[i] : KEY_EMPTY;
@@ -127,7 +178,13 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(const SelectPara
             if (p.out_keys) p.out_keys[out + i] = KEY_EMPTY;
         }
     }
-    if (tid == 0) p.out_count[sq.out_slot] = (int32_t) m;
+    if (tid == 0) {
+        p.out_count[sq.out_slot] = (int32_t) m;
+        if (p.seeded && m < k && m < sq.allowed) {           // a seeded threshold cut below the k-th result
+            p.out_flags[sq.out_slot] = 1;
+            atomicAdd(p.flagged_total, 1);
+        }
+    }
 }
 
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, hipStream_t s)
@@ -362,6 +419,156 @@ hipError_t launch_pair_distances(const float* a, const float* b, int64_t n_pairs
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pair_distance_kernel, dim3((uint32_t) blocks), dim3(256), 0, s, a, b, n_pairs, dim,
                        b_broadcast, metric, out);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// K5r: exact re-rank after K2's screening.  One workgroup per query; one wave per candidate recomputes the
+// operator arithmetic of vector.c (fp32 accumulation, float8 post-processing), then the kp exact keys are
+// sorted and the first k reported.  A query is flagged when a row OUTSIDE the kept set could still beat the
+// k-th result, i.e. when  (worst kept screening value) - err  <=  (k-th exact value),  err = fp32 error bound of
+// the screening arithmetic for this corpus (|x|^2 <= norm2_max).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                   // [np2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t out_slot = p.queries[slot].out_slot;
+    const uint64_t* list = p.lists + (size_t) slot * p.kp;
+    const float4* q = reinterpret_cast<const float4*>(p.queries_f) + (size_t) slot * p.stride4;
+    uint32_t np2 = 2;
+    while (np2 < p.kp) np2 <<= 1;
+
+    float qn_part = 0.0f;
+    for (uint32_t c = lane; c < p.stride4; c += 64) {
+        const float4 v = q[c];
+        qn_part = fmaf(v.x, v.x, qn_part); qn_part = fmaf(v.y, v.y, qn_part);
+        qn_part = fmaf(v.z, v.z, qn_part); qn_part = fmaf(v.w, v.w, qn_part);
+    }
+    for (int m = 32; m >= 1; m >>= 1) qn_part += __shfl_xor(qn_part, m);
+    const float qn = qn_part;
+
+    for (uint32_t c = wave; c < np2; c += 4) {
+        uint64_t out = KEY_EMPTY;
+        const uint64_t sk = c < p.kp ? list[c] : KEY_EMPTY;
+        if (sk != KEY_EMPTY) {                                             // wave-uniform
+            const uint32_t row = (uint32_t) sk;
+            const float4* x = p.rows + (size_t) row * p.stride4;
+            float s = 0.0f, nx = 0.0f;
+            for (uint32_t ch = lane; ch < p.stride4; ch += 64) {
+                const float4 a = x[ch], b = q[ch];
+                if (p.metric == M_L2) {
+                    const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+                    s = fmaf(d0, d0, s); s = fmaf(d1, d1, s); s = fmaf(d2, d2, s); s = fmaf(d3, d3, s);
+                } else {
+                    s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+                    if (p.metric == M_COSINE) {
+                        nx = fmaf(a.x, a.x, nx); nx = fmaf(a.y, a.y, nx); nx = fmaf(a.z, a.z, nx); nx = fmaf(a.w, a.w, nx);
+                    }
+                }
+            }
+            for (int m = 32; m >= 1; m >>= 1) {
+                s += __shfl_xor(s, m);
+                nx += __shfl_xor(nx, m);
+            }
+            float v;
+            if (p.metric == M_L2) v = s;
+            else if (p.metric == M_IP) v = -s;
+            else {
+                double sim = (double) s / sqrt((double) nx * (double) qn);
+                if (sim > 1.0) sim = 1.0; else if (sim < -1.0) sim = -1.0;
+                v = (float) (1.0 - sim);
+            }
+            out = make_key(v, row);
+        }
+        if (lane == 0) keys[c] = out;
+    }
+    __syncthreads();
+    bitonic_sort_lds<256>(keys, np2, tid);
+
+    // how many exact keys exist, and the flag
+    __shared__ uint32_t s_count;
+    if (tid == 0) {
+        uint32_t lo = 0, hi = p.kp < np2 ? p.kp : np2;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (keys[mid] != KEY_EMPTY) lo = mid + 1; else hi = mid;
+        }
+        s_count = lo;
+        int flag = 0;
+        // every row outside the kept set ranks at or after `bound` in screening value: the worst kept candidate when
+        // the list is full, else the seeded threshold (if any), else there is no outside row at all
+        const uint64_t worst_kept = list[p.kp - 1];                        // screening keys are ascending
+        uint64_t bound = worst_kept;
+        if (bound == KEY_EMPTY && p.seeded) bound = p.tau_init[slot];
+        if (bound != KEY_EMPTY) {
+            const uint32_t allowed = p.queries[slot].allowed;
+            if (lo < p.k) {
+                if (lo < allowed) flag = 1;                                // the threshold cut below the k-th result
+            } else {
+                const float a_last = mono_to_float((uint32_t) (bound >> 32));
+                const float d_k = mono_to_float((uint32_t) (keys[p.k - 1] >> 32));
+                const float g = (float) (p.dim + 8) * 5.9604645e-8f;       // (d + 8) * 2^-24
+                const float nxm = *p.norm2_max;
+                float err;
+                if (p.metric == M_L2) err = 2.0f * g * (nxm + qn) + g * fabsf(a_last);
+                else if (p.metric == M_IP) err = 2.0f * g * sqrtf(nxm * qn);
+                else err = 8.0f * g;
+                if (!(a_last - err > d_k)) flag = 1;                       // also catches NaN
+            }
+        }
+        p.out_flags[out_slot] = flag;
+        if (flag) atomicAdd(p.flagged_total, 1);
+    }
+    __syncthreads();
+    const uint32_t m = s_count < p.k ? s_count : p.k;
+    const size_t o = (size_t) out_slot * p.k;
+    for (uint32_t i = tid; i < p.k; i += 256) {
+        if (i < m) {
+            const uint64_t key = keys[i];
+            const uint32_t row = (uint32_t) key;
+            const float v = mono_to_float((uint32_t) (key >> 32));
+            p.out_block[o + i] = p.block_ids[row];
+            p.out_doc[o + i] = p.doc_ids[row];
+            if (p.out_row) p.out_row[o + i] = p.orig_rows[row];
+            p.out_dist[o + i] = output_distance(p.metric, v);
+            if (p.out_keys) p.out_keys[o + i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t) (row + p.row_offset);
+        } else {
+            p.out_block[o + i] = -1;
+            p.out_doc[o + i] = -1;
+            if (p.out_row) p.out_row[o + i] = -1;
+            p.out_dist[o + i] = __builtin_inff();
+            if (p.out_keys) p.out_keys[o + i] = KEY_EMPTY;
+        }
+    }
+    if (tid == 0) p.out_count[out_slot] = (int32_t) m;
+}
+
+hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s)
+{
+    uint32_t np2 = 2;
+    while (np2 < p.kp) np2 <<= 1;
+    hipLaunchKernelGGL(rerank_kernel, dim3(n_queries), dim3(256), (size_t) np2 * sizeof(uint64_t), s, p);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void norm_max_kernel(const float* norm2, uint32_t n, uint32_t* out_bits)
+{
+    float m = 0.0f;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = fmaxf(m, norm2[i]);
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order as uints
+}
+
+hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out_max, 0, sizeof(float), s);
+    if (e != hipSuccess || n == 0) return e;
+    uint32_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(norm_max_kernel, dim3(blocks), dim3(256), 0, s, norm2, n, reinterpret_cast<uint32_t*>(out_max));
     return hipGetLastError();
 }
 

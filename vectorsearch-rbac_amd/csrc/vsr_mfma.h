@@ -1,0 +1,290 @@
+// vsr_mfma.h — K2: shared-pass scan on the matrix cores (fp32 MFMA screening) + exact re-rank (K5r).
+//
+// For passes that many queries share, the distance work is GEMM-shaped: dot[row][query] = sum_k x[row][k] * q[query][k].
+// K2 computes the dot products with v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, one VGPR per operand; 16 rows x
+// 16 queries per instruction group) and turns them into SCREENING keys
+//     L2:  |x|^2 + |q|^2 - 2 dot        IP: -dot        cosine: 1 - dot * rsqrt(|x|^2 |q|^2)
+// whose only job is to keep, per query, the kp (= 2k) best candidates.  The expansion form of L2 cancels for
+// near-duplicates, so screening keys are never reported: K5r (rerank_kernel, vsr_kernels.hip) recomputes the
+// exact operator arithmetic of vector.c:549-563 / :596-606 / :638-685 for the kp survivors, selects the final k and
+// flags a query when the gap between the kept set and the rest is inside the fp32 error bound of the screening
+// (then the caller re-runs that query on the exact K1 path).  On integer-valued data the expansion is exact.
+//
+// Data path per wave and 64-row tile: coalesced global loads (256-byte row segments) -> wave-private LDS image,
+// XOR-swizzled so that the A-fragment reads (lane = (row i, k-quad kq) reads float4 [i][4t+kq]) are conflict-free
+// -> 4 x 16-row sub-tiles x 4 k-steps of MFMA per float4.  The 16 query vectors sit in registers as B fragments
+// for the whole kernel when d <= 256 (32 VGPRs at d = 128), else they are re-read from LDS.
+#pragma once
+#include "vsr_device.h"
+#include "vsr_scan.h"
+#include "vsr_topk.h"
+
+namespace vsr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int MF_THREADS = 256;
+constexpr int MF_WAVES = 4;
+constexpr int MF_S = 16;                  // float4 chunks per stage
+constexpr int MF_NQ = 16;                 // query columns of one MFMA tile
+constexpr int MF_SLACK = MF_WAVES * 64;   // keys per query a workgroup can append between two votes
+
+template <int METRIC>
+__device__ __forceinline__ float screen_value(float dot, float nx, float nq)
+{
+    if constexpr (METRIC == M_L2) return fmaf(-2.0f, dot, nx + nq);
+    else if constexpr (METRIC == M_IP) return -dot;
+    else return 1.0f - dot * rsqrtf(nx * nq);
+}
+
+// NSTR > 0: B fragments of NSTR stages live in registers (d <= 64 * NSTR); NSTR == 0: B read from LDS per use.
+// SAMPLE only gives the seeding pass (p.sample_stride > 1) its own kernel symbol in profiles.
+template <int METRIC, int NSTR, bool SAMPLE>
+__global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    uint32_t lo = 0, hi = p.n_groups;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (p.groups[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const ScanGroup grp = p.groups[lo];
+    const uint32_t local_block = blockIdx.x - grp.block_begin;
+
+    const uint32_t stride4 = p.stride4, cap = p.cap, keep = p.k;
+    const uint32_t nstage = (stride4 + MF_S - 1) / MF_S;
+    const uint32_t qpitch = nstage * MF_S;
+    const uint32_t q_count = grp.q_count;
+
+    float4*   stage = reinterpret_cast<float4*>(smem) + (size_t) wave * 64 * MF_S;
+    unsigned char* after = smem + (size_t) MF_WAVES * 64 * MF_S * 16;
+    int32_t*  rowidx = reinterpret_cast<int32_t*>(after) + wave * 64;
+    float*    rownorm = reinterpret_cast<float*>(after + MF_WAVES * 64 * 4) + wave * 64;
+    float4*   qlds = reinterpret_cast<float4*>(after + MF_WAVES * 64 * 8);
+    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(qlds + (size_t) MF_NQ * qpitch);
+    float*    qnl = reinterpret_cast<float*>(ctrl + MF_NQ);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(qnl + MF_NQ);
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem);
+
+    for (uint32_t qi = tid; qi < (uint32_t) MF_NQ; qi += MF_THREADS) {
+        const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
+        ctrl[qi].count = 0;
+        qnl[qi] = p.q_norm2[slot];
+        if (p.dbg && p.tau_init && qi < q_count && local_block == 0)
+            atomicAdd(&p.dbg[p.tau_init[slot] == KEY_EMPTY ? 3 : 4], 1ull);
+    }
+    if (tid < 4) flags[tid] = 0;
+    for (uint32_t qi = 0; qi < (uint32_t) MF_NQ; ++qi) {                       // pad columns repeat query 0
+        const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
+        for (uint32_t i = tid; i < qpitch; i += MF_THREADS)
+            qlds[(size_t) qi * qpitch + i] = i < stride4 ? qsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    // MFMA lane roles: A operand lane = (row i, k-quad kq); B operand / result lane = (k-quad kq, query jq)
+    const int li = lane & 15;
+    const int kq = lane >> 4;
+    const int jq = li;
+    constexpr int NB = NSTR > 0 ? NSTR : 1;
+    float4 bq[NB][4];
+    if constexpr (NSTR > 0) {
+#pragma unroll
+        for (int s = 0; s < NSTR; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                bq[s][t] = (uint32_t) s < nstage ? qlds[(size_t) jq * qpitch + s * MF_S + 4 * t + kq]
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float my_qn = qnl[jq];
+
+    const uint32_t rw = p.rw, tps = 64 / rw;
+    const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
+    const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
+    const uint32_t n_super = (t1 - t0 + tps - 1) / tps;
+    const uint32_t ss = p.sample_stride;                                       // sample pass: every ss-th super-tile
+    const uint32_t iters = ((n_super + ss - 1) / ss + MF_WAVES - 1) / MF_WAVES;
+    const uint32_t trigger = cap - MF_SLACK;
+    uint64_t* cand = p.cand + (size_t) (grp.partial_begin + local_block) * cap;
+    const size_t cand_qstride = (size_t) grp.n_blocks * cap;
+
+    const int lps_row = lane / MF_S, lps_chunk = lane % MF_S;
+    constexpr int RPI = 64 / MF_S;
+
+    uint32_t round = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t sup = (it * MF_WAVES + wave) * ss;
+        int32_t myrow = -1;
+        if (sup < n_super) {
+            const uint32_t t = t0 + sup * tps + (uint32_t) lane / rw;
+            const uint32_t r = (uint32_t) lane % rw;
+            if (t < t1) {
+                uint32_t start, nrows;
+                if (grp.tiles) {
+                    const uint2 tl = grp.tiles[t];
+                    start = tl.x;
+                    nrows = tl.y;
+                } else {
+                    start = t * rw;
+                    nrows = p.n_rows - start < rw ? p.n_rows - start : rw;
+                }
+                if (r < nrows) {
+                    const uint32_t row = start + r;
+                    bool ok = true;
+                    if (grp.bitmap) ok = (grp.bitmap[row >> 6] >> (row & 63)) & 1ull;
+                    if (ok) myrow = (int32_t) row;
+                }
+            }
+        }
+        if (__ballot(myrow >= 0) != 0) {                                       // wave-uniform
+            if (p.dbg && lane == 0) atomicAdd(&p.dbg[2], 1ull);
+            rowidx[lane] = myrow;
+            rownorm[lane] = myrow >= 0 ? p.norm2[myrow] : 0.0f;
+
+            f32x4 acc[4];
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) acc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            float4 x[MF_S];
+            auto issue = [&](uint32_t s) {
+                const uint32_t chunk = s * MF_S + lps_chunk;
+#pragma unroll
+                for (int u = 0; u < MF_S; ++u) {
+                    const int32_t r = rowidx[u * RPI + lps_row];
+                    x[u] = (r >= 0 && chunk < stride4) ? p.rows[(size_t) r * stride4 + chunk]
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            issue(0);
+            for (uint32_t s = 0; s < nstage; ++s) {
+#pragma unroll
+                for (int u = 0; u < MF_S; ++u) {
+                    const int row = u * RPI + lps_row;
+                    stage[row * MF_S + (lps_chunk ^ (row & 15))] = x[u];       // swizzled image
+                }
+                if (s + 1 < nstage) issue(s + 1);                              // in flight during the MFMAs
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float4 b;
+                    if constexpr (NSTR > 0) {
+                        b = bq[0][t];
+#pragma unroll
+                        for (int ss = 1; ss < NSTR; ++ss)
+                            if (s == (uint32_t) ss) b = bq[ss][t];
+                    } else {
+                        b = qlds[(size_t) jq * qpitch + s * MF_S + 4 * t + kq];
+                    }
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        const int row = sub * 16 + li;
+                        const float4 a = stage[row * MF_S + ((4 * t + kq) ^ li)];
+                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[sub], 0, 0, 0);
+                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[sub], 0, 0, 0);
+                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[sub], 0, 0, 0);
+                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[sub], 0, 0, 0);
+                    }
+                }
+            }
+
+            // results: acc[sub][r] = dot(row sub*16 + kq*4 + r, query jq).  Every lane screens its 16 (row, query jq)
+            // pairs, then reserves room for all of its survivors with ONE LDS atomic and stores them: no atomic
+            // round trip per pair.
+            const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[jq].tau);
+            const bool qok = (uint32_t) jq < q_count && !(p.debug & 1u);
+            uint64_t keyv[16];
+            uint32_t pmask = 0;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const int4 ri = *reinterpret_cast<const int4*>(&rowidx[sub * 16 + kq * 4]);
+                const float4 rn = *reinterpret_cast<const float4*>(&rownorm[sub * 16 + kq * 4]);
+                const int32_t rows4[4] = {ri.x, ri.y, ri.z, ri.w};
+                const float nx4[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = screen_value<METRIC>(acc[sub][r], nx4[r], my_qn);
+                    keyv[sub * 4 + r] = make_key(v, (uint32_t) rows4[r]);
+                    if (qok && rows4[r] >= 0 && keyv[sub * 4 + r] < tau) pmask |= 1u << (sub * 4 + r);
+                }
+            }
+            if (__ballot(pmask != 0) != 0) {                                   // wave-uniform
+                uint32_t base = 0;
+                if (pmask) base = atomicAdd(&ctrl[jq].count, (uint32_t) __popc(pmask));
+                if (p.dbg && pmask) atomicAdd(&p.dbg[1], (unsigned long long) __popc(pmask));
+                uint64_t* dst = cand + (size_t) jq * cand_qstride + base;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (pmask & (1u << i)) dst[__popc(pmask & ((1u << i) - 1u))] = keyv[i];
+            }
+        }
+
+        if (it + 1 < iters) {
+            bool need = false;
+            for (uint32_t q = 0; q < q_count; ++q)
+                need |= *reinterpret_cast<volatile uint32_t*>(&ctrl[q].count) > trigger;
+            const uint32_t slot = round % 3;
+            if (need && lane == 0) atomicOr(&flags[slot], 1u);
+            __syncthreads();
+            const bool any = *reinterpret_cast<volatile uint32_t*>(&flags[slot]) != 0;
+            if (tid == 0) flags[(round + 2) % 3] = 0;
+            ++round;
+            if (any) {
+                for (uint32_t q = 0; q < q_count; ++q) {
+                    const uint32_t n = ctrl[q].count;
+                    if (n > trigger) {                                         // only the buffers that are filling up
+                        if (p.dbg && tid == 0) atomicAdd(&p.dbg[0], 1ull);
+                        uint64_t* cq = cand + (size_t) q * cand_qstride;
+                        for (uint32_t i = tid; i < n; i += MF_THREADS) sortbuf[i] = cq[i];
+                        __syncthreads();
+                        topk_compact<MF_THREADS>(sortbuf, &ctrl[q], keep, tid, false);
+                        for (uint32_t i = tid; i < keep; i += MF_THREADS) cq[i] = sortbuf[i];
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+    for (uint32_t q = 0; q < q_count; ++q) {
+        const uint32_t n = ctrl[q].count;
+        const uint64_t* cq = cand + (size_t) q * cand_qstride;
+        for (uint32_t i = tid; i < n; i += MF_THREADS) sortbuf[i] = cq[i];
+        __syncthreads();
+        topk_compact<MF_THREADS>(sortbuf, &ctrl[q], keep, tid, false);
+        const uint32_t m = ctrl[q].count < keep ? ctrl[q].count : keep;
+        uint64_t* dst = p.partial + (size_t) (grp.partial_begin + q * grp.n_blocks + local_block) * p.kp;
+        for (uint32_t i = tid; i < p.kp; i += MF_THREADS) dst[i] = i < m ? sortbuf[i] : KEY_EMPTY;
+        __syncthreads();
+    }
+}
+
+template <int METRIC>
+hipError_t launch_mfma_metric(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
+{
+    const size_t lds = mfma_lds_bytes(p.stride4);
+    const uint32_t nstage = (p.stride4 + MF_S - 1) / MF_S;
+    auto launch = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(MF_THREADS), lds, s, p);
+        return hipGetLastError();
+    };
+    if (p.sample_stride > 1) {
+        if (nstage <= 2) return launch(mfma_scan_kernel<METRIC, 2, true>);
+        if (nstage <= 4) return launch(mfma_scan_kernel<METRIC, 4, true>);
+        return launch(mfma_scan_kernel<METRIC, 0, true>);
+    }
+    if (nstage <= 2) return launch(mfma_scan_kernel<METRIC, 2, false>);
+    if (nstage <= 4) return launch(mfma_scan_kernel<METRIC, 4, false>);
+    return launch(mfma_scan_kernel<METRIC, 0, false>);
+}
+
+}  // namespace vsr

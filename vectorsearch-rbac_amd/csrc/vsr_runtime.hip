@@ -23,6 +23,11 @@ using namespace vsr;
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
+// threshold seeding (see search_impl): the sample pass visits every SEED_STRIDE-th tile with 1/SEED_BLOCK_DIV of
+// the workgroups (measured on MI355X: 256 / 1 is the cheapest sample that still seeds tightly)
+static uint32_t SEED_STRIDE = 256;
+static uint32_t SEED_BLOCK_DIV = 1;
+
 static int fail(int status, const char* fmt, ...)
 {
     char buf[512];
@@ -106,6 +111,14 @@ struct vsr_ctx {
     // workspaces
     DevBuf d_desc;       // queries (padded) + q norms + scan groups + select queries, one upload
     DevBuf d_partial;
+    DevBuf d_cand;       // K1m / K2 candidate buffers
+    DevBuf d_flags;      // per-query screening flags of the last call
+    DevBuf d_tau;        // seeded thresholds (sample pass)
+    bool   seeding = true;        // seed thresholds of big shared passes from a 1/32 sample pass
+    int64_t seed_min_rows = 2000000;
+    int32_t* d_flag_total = nullptr;   // running count of flagged queries (device)
+    bool   screening = true;      // allow K2 (MFMA screening + exact re-rank) for shared passes
+    int64_t flagged_seen = 0;
     DevBuf d_out;        // host-API outputs
     DevBuf d_misc;
     PinBuf h_desc;
@@ -121,6 +134,10 @@ struct vsr_ctx {
     int block_budget = 0;          // 0 = 4 * CUs
     int min_rows_per_block = 256;
     int max_qb = SCAN_QMAX;
+    uint32_t debug = 0;            // VSR_DEBUG bits (measurement only)
+    double extra_ms[2] = {0, 0};   // sample scan, seed select (profiling only)
+    unsigned long long* d_dbg = nullptr;
+    bool no_mq = false;            // VSR_NO_MQ=1: keep shared passes on K1 (A/B measurements)
 };
 
 struct vsr_filter {
@@ -144,6 +161,7 @@ struct vsr_corpus {
     KernelShape shape{};
     float4*     d_rows = nullptr;
     float*      d_norm2 = nullptr;
+    float*      d_norm2_max = nullptr;   // max |row|^2 (error bound of K2 screening)
     int64_t*    d_block = nullptr;
     int32_t*    d_doc = nullptr;
     int64_t*    d_orig = nullptr;
@@ -204,10 +222,18 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIPCHK(hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming));
+    HIPCHK(hipMalloc(&ctx->d_flag_total, 64));
+    HIPCHK(hipMemset(ctx->d_flag_total, 0, 64));
     const char* env;
     if ((env = getenv("VSR_BLOCK_BUDGET"))) ctx->block_budget = atoi(env);
     if ((env = getenv("VSR_MIN_ROWS_PER_BLOCK"))) ctx->min_rows_per_block = std::max(1, atoi(env));
     if ((env = getenv("VSR_MAX_QB"))) ctx->max_qb = std::max(1, atoi(env));
+    if ((env = getenv("VSR_NO_MQ"))) ctx->no_mq = atoi(env) != 0;
+    if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
+    if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
+    if ((env = getenv("VSR_SEED_STRIDE"))) SEED_STRIDE = (uint32_t) std::max(2, atoi(env));
+    if ((env = getenv("VSR_SEED_DIV"))) SEED_BLOCK_DIV = (uint32_t) std::max(1, atoi(env));
+    if ((env = getenv("VSR_NO_SCREENING"))) ctx->screening = atoi(env) == 0;
     *out = ctx.release();
     return VSR_OK;
 }
@@ -224,11 +250,15 @@ extern "C" int vsr_close(vsr_ctx* ctx)
     for (auto ev : ctx->event_pool) (void) hipEventDestroy(ev);
     ctx->d_desc.release();
     ctx->d_partial.release();
+    ctx->d_cand.release();
+    ctx->d_flags.release();
+    ctx->d_tau.release();
     ctx->d_out.release();
     ctx->d_misc.release();
     ctx->h_desc.release();
     ctx->h_out.release();
     if (ctx->desc_done) (void) hipEventDestroy(ctx->desc_done);
+    if (ctx->d_flag_total) (void) hipFree(ctx->d_flag_total);
     if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VSR_OK;
@@ -286,7 +316,9 @@ static void drain_events(vsr_ctx* ctx)
     for (auto& ep : ctx->pending) {
         float ms = 0.f;
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
-            if (ep.kind < 2) {
+            if (ep.kind >= 3) {
+                ctx->extra_ms[ep.kind - 3] += ms;
+            } else if (ep.kind < 2) {
                 ctx->stats.scan_ms[ep.kind] += ms;
                 ctx->stats.scan_launches[ep.kind]++;
             } else {
@@ -313,6 +345,15 @@ extern "C" int vsr_stats_get(vsr_ctx* ctx, vsr_stats* out)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     drain_events(ctx);
     *out = ctx->stats;
+    if (ctx->d_dbg) {
+        unsigned long long h[5] = {0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpy(h, ctx->d_dbg, sizeof h, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(ctx->d_dbg, 0, 64));
+        fprintf(stderr, "[vsr debug] sample_scan_ms=%.3f seed_select_ms=%.3f\n", ctx->extra_ms[0], ctx->extra_ms[1]);
+        ctx->extra_ms[0] = ctx->extra_ms[1] = 0;
+        fprintf(stderr, "[vsr debug] compactions=%llu appended=%llu tiles=%llu seeds_empty=%llu seeds_set=%llu\n", h[0], h[1],
+                h[2], h[3], h[4]);
+    }
     return VSR_OK;
 }
 
@@ -339,7 +380,7 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
         if (f->d_bitmap && f->owns_bitmap) (void) hipFree(f->d_bitmap);
         delete f;
     }
-    void* ptrs[] = {c->d_rows, c->d_norm2, c->d_block, c->d_doc, c->d_orig, c->d_row_docidx, c->d_doc_mask};
+    void* ptrs[] = {c->d_rows, c->d_norm2, c->d_norm2_max, c->d_block, c->d_doc, c->d_orig, c->d_row_docidx, c->d_doc_mask};
     for (void* p : ptrs)
         if (p) (void) hipFree(p);
     delete c;
@@ -404,6 +445,8 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
     const size_t alloc_rows = (size_t) std::max<int64_t>(n, 1);
     HIPCHK(hipMalloc(&c->d_rows, alloc_rows * row_bytes + 1024));
     HIPCHK(hipMalloc(&c->d_norm2, alloc_rows * sizeof(float)));
+    HIPCHK(hipMalloc(&c->d_norm2_max, 64));
+    HIPCHK(hipMemset(c->d_norm2_max, 0, 64));
     HIPCHK(hipMalloc(&c->d_block, alloc_rows * sizeof(int64_t)));
     HIPCHK(hipMalloc(&c->d_doc, alloc_rows * sizeof(int32_t)));
     HIPCHK(hipMalloc(&c->d_orig, alloc_rows * sizeof(int64_t)));
@@ -431,6 +474,7 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
         HIPCHK(hipMemcpy(c->d_orig, perm.data(), (size_t) n * sizeof(int64_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_row_docidx, h_docidx.data(), (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIPCHK(launch_row_norms(c->d_rows, (uint32_t) n, c->stride4, c->d_norm2, ctx->stream));
+        HIPCHK(launch_norm_max(c->d_norm2, (uint32_t) n, c->d_norm2_max, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     *out = c.release();
@@ -757,16 +801,24 @@ extern "C" int64_t vsr_filter_scanned_rows(const vsr_filter* f) { return f ? f->
 namespace {
 
 constexpr uint32_t SEL_FANIN = 64;           // partial lists one K5 workgroup merges; more -> two levels
-constexpr uint32_t SEL_FINAL = 0xFFFFFFFFu;
 
 struct Plan {
     std::vector<uint32_t>    slot_query;     // slot -> caller query index
     std::vector<ScanGroup>   groups;         // one K1 launch
     uint32_t                 n_blocks = 0;
     int                      qi = 1;         // kernel sub-batch width (1 or 4)
+    bool                     mq = false;     // shared passes run on K1m (vsr_mq.h)
+    bool                     k2 = false;     // shared passes run on K2 (MFMA screening) + K5r
+    uint32_t                 keep = 0;       // K2: candidates kept per query (kp)
+    uint32_t                 rerank_base = 0;  // K2: first partial list holding the per-query screening survivors
+    uint32_t                 n_scan_lists = 0;
     uint32_t                 qmax = 1;       // query slots per workgroup
     std::vector<SelectQuery> sel1;           // level-1 K5 items (only for queries with many partial lists)
     std::vector<SelectQuery> selq;           // final K5 item per query (slot order)
+    std::vector<ScanGroup>   groups_s;       // sample pass (threshold seeding): same passes, fewer workgroups
+    std::vector<SelectQuery> seedq;          // per query: merge the sample pass's lists into a seed threshold
+    uint32_t                 n_blocks_s = 0;
+    uint32_t                 n_partial_s = 0;
     uint32_t                 n_partial = 0;  // K1 partial lists + level-1 K5 outputs
     int64_t                  scan_rows = 0;
     int64_t                  scan_bytes = 0;
@@ -781,7 +833,8 @@ struct PassDesc {
 
 }  // namespace
 
-static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* const* filters, Plan& plan)
+static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow_screening,
+                      const vsr_filter* const* filters, Plan& plan)
 {
     const vsr_ctx* ctx = c->ctx;
     // queries sharing a filter share corpus passes: order slots by filter
@@ -791,7 +844,12 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fof(a) < fof(b); });
     plan.slot_query = order;
 
-    int qmax = std::min(ctx->max_qb, scan_qmax(c->dim, k));
+    const bool mq_ok = mq_supported(c->dim) && mq_qmax(c->dim) >= 4 && !ctx->no_mq;
+    // K2: matrix-core screening keeps 2k (>= 32) candidates per query, K5r re-ranks them exactly
+    const uint32_t keep = (uint32_t) std::max(2 * k, 32);
+    const bool k2_ok = allow_screening && ctx->screening && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
+                       2 * keep + 256 <= 8192 && ctx->max_qb >= 16 && mfma_lds_bytes(c->stride4) <= 150 * 1024;
+    int qmax = k2_ok ? 16 : std::min(ctx->max_qb, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
     qmax = qmax >= 4 ? qmax / 4 * 4 : 1;
     std::vector<PassDesc> passes;
     uint32_t widest = 1;
@@ -816,6 +874,10 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
     // one launch: the 4-wide kernel as soon as any pass carries more than one query
     plan.qi = widest > 1 ? 4 : 1;
     plan.qmax = plan.qi == 1 ? 1 : (widest + 3) / 4 * 4;
+    plan.k2 = plan.qi == 4 && k2_ok;
+    plan.mq = plan.qi == 4 && mq_ok && !plan.k2;
+    plan.keep = plan.k2 ? keep : (uint32_t) k;
+    if (plan.k2) plan.qmax = 16;
 
     int64_t total_rows = 0;
     for (auto& p : passes) total_rows += std::max<int64_t>(p.rows, 1);
@@ -834,6 +896,8 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
             sq.n_lists = empty ? 0 : (uint32_t) nb;
             sq.out_slot = order[p.q_begin + qi];
             sq.dst_list = SEL_FINAL;
+            sq.allowed = (uint32_t) std::min<int64_t>(p.f ? p.f->allowed_rows : c->n, 0xFFFFFFFFll);
+            sq.pad = 0;
             plan.selq[p.q_begin + qi] = sq;
         }
         if (empty) continue;
@@ -847,11 +911,32 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
         g.n_blocks = (uint32_t) nb;
         g.partial_begin = plan.n_partial;
         plan.groups.push_back(g);
+        {   // the same pass in the sample launch (aliases the partial / candidate buffers: it finishes first)
+            ScanGroup gs = g;
+            gs.n_blocks = (uint32_t) std::max<int64_t>(1, nb / SEED_BLOCK_DIV);
+            gs.block_begin = plan.n_blocks_s;
+            gs.partial_begin = plan.n_partial_s;
+            plan.groups_s.push_back(gs);
+            for (uint32_t qi = 0; qi < p.q_count; ++qi) {
+                SelectQuery sd;
+                sd.partial_begin = plan.n_partial_s + qi * gs.n_blocks;
+                sd.n_lists = gs.n_blocks;
+                sd.out_slot = p.q_begin + qi;          // thresholds are indexed by slot
+                sd.dst_list = SEL_SEED;
+                sd.allowed = 0;
+                sd.pad = 0;
+                plan.seedq.push_back(sd);
+            }
+            plan.n_blocks_s += gs.n_blocks;
+            plan.n_partial_s += gs.n_blocks * p.q_count;
+        }
         plan.n_blocks += (uint32_t) nb;
         plan.n_partial += (uint32_t) nb * p.q_count;
         plan.scan_rows += p.rows;
-        plan.scan_bytes += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12;
+        plan.scan_bytes += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12 +
+                           (plan.k2 ? p.rows * 4 : 0);     // K2 also reads |row|^2
     }
+    plan.n_scan_lists = plan.n_partial;
     // queries with many partial lists get a first K5 level of SEL_FANIN-list merges
     for (auto& sq : plan.selq) {
         if (sq.n_lists <= SEL_FANIN) continue;
@@ -862,11 +947,18 @@ static void make_plan(const vsr_corpus* c, int nq, int k, const vsr_filter* cons
             s1.n_lists = std::min<uint32_t>(SEL_FANIN, sq.n_lists - j * SEL_FANIN);
             s1.out_slot = 0;
             s1.dst_list = plan.n_partial + j;
+            s1.allowed = 0;
+            s1.pad = 0;
             plan.sel1.push_back(s1);
         }
         sq.partial_begin = plan.n_partial;
         sq.n_lists = n1;
         plan.n_partial += n1;
+    }
+    if (plan.k2) {          // the final K5 of every query writes its kp screening survivors as list rerank_base + slot
+        plan.rerank_base = plan.n_partial;
+        for (size_t s = 0; s < plan.selq.size(); ++s) plan.selq[s].dst_list = plan.rerank_base + (uint32_t) s;
+        plan.n_partial += (uint32_t) plan.selq.size();
     }
 }
 
@@ -875,13 +967,13 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // Shared by the host and device entry points.  d_queries == nullptr: queries come from `h_queries`.
 static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_queries, int nq, int dim, int k, int metric,
                        const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row, float* d_dist,
-                       int32_t* d_cnt, uint64_t* d_keys)
+                       int32_t* d_cnt, uint64_t* d_keys, bool allow_screening)
 {
     vsr_ctx* ctx = c->ctx;
     Plan plan;
-    make_plan(c, nq, k, filters, plan);
+    make_plan(c, nq, k, metric, allow_screening, filters, plan);
 
-    const uint32_t kp = (uint32_t) k;
+    const uint32_t kp = plan.keep;
     const size_t qfloats = (size_t) c->stride4 * 4;
     // one staging block: [queries | q_norm2 | scan groups | level-1 select | final select | slot map]
     const size_t off_q = 0;
@@ -889,7 +981,9 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     const size_t off_g = align_up(off_qn + (size_t) nq * sizeof(float), 256);
     const size_t off_s1 = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
     const size_t off_sq = align_up(off_s1 + plan.sel1.size() * sizeof(SelectQuery), 256);
-    const size_t off_sl = align_up(off_sq + plan.selq.size() * sizeof(SelectQuery), 256);
+    const size_t off_gs = align_up(off_sq + plan.selq.size() * sizeof(SelectQuery), 256);   // sample-pass groups
+    const size_t off_sd = align_up(off_gs + plan.groups_s.size() * sizeof(ScanGroup), 256); // seed items
+    const size_t off_sl = align_up(off_sd + plan.seedq.size() * sizeof(SelectQuery), 256);
     const size_t total = align_up(off_sl + (size_t) nq * sizeof(uint32_t), 256);
 
     int rc;
@@ -914,6 +1008,8 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     memcpy(hs + off_g, plan.groups.data(), plan.groups.size() * sizeof(ScanGroup));
     memcpy(hs + off_s1, plan.sel1.data(), plan.sel1.size() * sizeof(SelectQuery));
     memcpy(hs + off_sq, plan.selq.data(), plan.selq.size() * sizeof(SelectQuery));
+    memcpy(hs + off_gs, plan.groups_s.data(), plan.groups_s.size() * sizeof(ScanGroup));
+    memcpy(hs + off_sd, plan.seedq.data(), plan.seedq.size() * sizeof(SelectQuery));
     memcpy(hs + off_sl, plan.slot_query.data(), (size_t) nq * sizeof(uint32_t));
     if (h_queries) {
         HIPCHK(hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream));
@@ -935,38 +1031,37 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sp.q_norm2 = reinterpret_cast<const float*>(ds + off_qn);
     sp.partial = ctx->d_partial.as<uint64_t>();
     sp.kp = kp;
-    sp.k = (uint32_t) k;
-    sp.cap = scan_cap_for_k(k, c->dim);
+    sp.k = kp;
+    sp.cap = scan_cap_for_k((int) kp, c->dim);
     sp.qmax = plan.qmax;
+    sp.rw = (uint32_t) c->shape.rw;
+    sp.cand = nullptr;
+    sp.debug = ctx->debug;
+    sp.dbg = nullptr;
+    if (ctx->debug & 2u) {
+        if (!ctx->d_dbg) {
+            HIPCHK(hipMalloc(&ctx->d_dbg, 64));
+            HIPCHK(hipMemset(ctx->d_dbg, 0, 64));
+        }
+        sp.dbg = ctx->d_dbg;
+    }
+    if (plan.mq || plan.k2) {
+        if ((rc = ctx->d_cand.reserve(std::max<size_t>(8, (size_t) plan.n_scan_lists * sp.cap * sizeof(uint64_t))))) return rc;
+        sp.cand = ctx->d_cand.as<uint64_t>();
+    }
     sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
     sp.n_groups = (uint32_t) plan.groups.size();
-    if (metric == VSR_METRIC_COSINE)   // |q|^2 with the same kernel that made the row norms
+    if ((rc = ctx->d_flags.reserve((size_t) nq * sizeof(int32_t)))) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_flags.p, 0, (size_t) nq * sizeof(int32_t), ctx->stream));
+    if (metric == VSR_METRIC_COSINE || plan.k2)   // |q|^2 with the same kernel that made the row norms
         HIPCHK(launch_row_norms(reinterpret_cast<const float4*>(sp.queries), (uint32_t) nq, c->stride4,
                                 reinterpret_cast<float*>(ds + off_qn), ctx->stream));
-
-    const int cls = plan.qi == 4 ? 1 : 0;
-    if (plan.n_blocks) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ctx->profiling) {
-            e0 = take_event(ctx);
-            e1 = take_event(ctx);
-            HIPCHK(hipEventRecord(e0, ctx->stream));
-        }
-        HIPCHK(launch_scan(sp, metric, c->dim, plan.qi, plan.n_blocks, ctx->stream));
-        if (e0) {
-            HIPCHK(hipEventRecord(e1, ctx->stream));
-            ctx->pending.push_back({e0, e1, cls});
-        }
-        ctx->stats.scan_bytes[cls] += plan.scan_bytes;
-        ctx->stats.scan_rows[cls] += plan.scan_rows;
-    }
 
     SelectParams sel;
     sel.partial = ctx->d_partial.as<uint64_t>();
     sel.kp = kp;
-    sel.k = (uint32_t) k;
     sel.cap = 2048;
-    while (sel.cap < (uint32_t) (2 * k + SELECT_THREADS)) sel.cap <<= 1;
+    while (sel.cap < (uint32_t) (2 * kp + SELECT_THREADS)) sel.cap <<= 1;
     sel.metric = metric;
     sel.row_offset = (uint32_t) c->row_offset;
     sel.block_ids = c->d_block;
@@ -978,6 +1073,75 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sel.out_dist = d_dist;
     sel.out_keys = d_keys;
     sel.out_count = d_cnt;
+    sel.out_flags = ctx->d_flags.as<int32_t>();
+    sel.flagged_total = ctx->d_flag_total;
+    sel.tau_out = nullptr;
+    sel.seeded = 0;
+
+    // ---- threshold seeding: a 1/32 sample pass of the same launch, then the m-th best sampled candidate of each
+    // query becomes the initial threshold of the main pass (all rows at or before it stay eligible; a query whose
+    // seed turns out too tight is flagged by K5 / K5r and re-run unseeded) ----
+    const bool seed = allow_screening && ctx->seeding && (plan.k2 || plan.mq) && plan.n_blocks > 0 &&
+                      plan.scan_rows >= ctx->seed_min_rows;
+    sp.sample_stride = 1;
+    sp.tau_init = nullptr;
+    if (seed) {
+        if ((rc = ctx->d_tau.reserve((size_t) nq * sizeof(uint64_t)))) return rc;
+        HIPCHK(hipMemsetAsync(ctx->d_tau.p, 0xFF, (size_t) nq * sizeof(uint64_t), ctx->stream));   // no seed by default
+        sp.sample_stride = SEED_STRIDE;
+        sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_gs);
+        sp.n_groups = (uint32_t) plan.groups_s.size();
+        hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr;
+        if (ctx->profiling) {
+            a0 = take_event(ctx); a1 = take_event(ctx); b0 = take_event(ctx); b1 = take_event(ctx);
+            HIPCHK(hipEventRecord(a0, ctx->stream));
+        }
+        if (plan.k2) HIPCHK(launch_mfma(sp, metric, plan.n_blocks_s, ctx->stream));
+        else HIPCHK(launch_mq(sp, metric, plan.n_blocks_s, ctx->stream));
+        if (a0) {
+            HIPCHK(hipEventRecord(a1, ctx->stream));
+            HIPCHK(hipEventRecord(b0, ctx->stream));
+        }
+        sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
+        sp.n_groups = (uint32_t) plan.groups.size();
+        // m-th best of a 1/SEED_STRIDE sample: mean lambda = kp / SEED_STRIDE rows of the true top-kp fall into the
+        // sample; lambda + 6 sigma + 4 makes a too-tight seed a ~1e-8 event (and a detected one: K5 / K5r flag it)
+        const double lambda = (double) kp / SEED_STRIDE;
+        const uint32_t m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
+        sel.k = std::min(m, kp);
+        sel.tau_out = ctx->d_tau.as<uint64_t>();
+        sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sd);
+        HIPCHK(launch_select(sel, (uint32_t) plan.seedq.size(), ctx->stream));
+        if (a0) {
+            HIPCHK(hipEventRecord(b1, ctx->stream));
+            ctx->pending.push_back({a0, a1, 3});
+            ctx->pending.push_back({b0, b1, 4});
+        }
+        sp.sample_stride = 1;
+        sp.tau_init = ctx->d_tau.as<uint64_t>();
+        sel.seeded = 1;
+    }
+
+    const int cls = plan.qi == 4 ? 1 : 0;
+    if (plan.n_blocks) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->profiling) {
+            e0 = take_event(ctx);
+            e1 = take_event(ctx);
+            HIPCHK(hipEventRecord(e0, ctx->stream));
+        }
+        if (plan.k2) HIPCHK(launch_mfma(sp, metric, plan.n_blocks, ctx->stream));
+        else if (plan.mq) HIPCHK(launch_mq(sp, metric, plan.n_blocks, ctx->stream));
+        else HIPCHK(launch_scan(sp, metric, c->dim, plan.qi, plan.n_blocks, ctx->stream));
+        if (e0) {
+            HIPCHK(hipEventRecord(e1, ctx->stream));
+            ctx->pending.push_back({e0, e1, cls});
+        }
+        ctx->stats.scan_bytes[cls] += plan.scan_bytes;
+        ctx->stats.scan_rows[cls] += plan.scan_rows;
+    }
+
+    sel.k = kp;
     hipEvent_t s0 = nullptr, s1 = nullptr;
     if (ctx->profiling) {
         s0 = take_event(ctx);
@@ -990,6 +1154,34 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     }
     sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
     HIPCHK(launch_select(sel, (uint32_t) nq, ctx->stream));
+    if (plan.k2) {
+        RerankParams rr;
+        rr.lists = ctx->d_partial.as<uint64_t>() + (size_t) plan.rerank_base * kp;
+        rr.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
+        rr.rows = c->d_rows;
+        rr.stride4 = c->stride4;
+        rr.queries_f = reinterpret_cast<const float*>(ds + off_q);
+        rr.kp = kp;
+        rr.k = (uint32_t) k;
+        rr.metric = metric;
+        rr.dim = c->dim;
+        rr.norm2_max = c->d_norm2_max;
+        rr.row_offset = (uint32_t) c->row_offset;
+        rr.block_ids = c->d_block;
+        rr.doc_ids = c->d_doc;
+        rr.orig_rows = c->d_orig;
+        rr.out_block = d_blk;
+        rr.out_doc = d_doc;
+        rr.out_row = d_row;
+        rr.out_dist = d_dist;
+        rr.out_keys = d_keys;
+        rr.out_count = d_cnt;
+        rr.seeded = seed ? 1 : 0;
+        rr.tau_init = seed ? ctx->d_tau.as<uint64_t>() : nullptr;
+        rr.out_flags = ctx->d_flags.as<int32_t>();
+        rr.flagged_total = ctx->d_flag_total;
+        HIPCHK(launch_rerank(rr, (uint32_t) nq, ctx->stream));
+    }
     if (s0) {
         HIPCHK(hipEventRecord(s1, ctx->stream));
         ctx->pending.push_back({s0, s1, 2});
@@ -1027,7 +1219,7 @@ extern "C" int vsr_search_device(vsr_corpus* c, const float* d_queries, int nq, 
         if ((rc = ctx->d_misc.reserve((size_t) nq * k * sizeof(int32_t)))) return rc;
         d_doc = ctx->d_misc.as<int32_t>();
     }
-    return search_impl(c, nullptr, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys);
+    return search_impl(c, nullptr, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys, true);
 }
 
 extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, int k, int metric,
@@ -1047,18 +1239,71 @@ extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, 
     if ((rc = ctx->d_out.reserve(total))) return rc;
     if ((rc = ctx->h_out.reserve(total))) return rc;
     char* d = ctx->d_out.as<char>();
-    rc = search_impl(c, queries, nullptr, nq, dim, k, metric, filters, reinterpret_cast<int64_t*>(d + o_blk),
-                     reinterpret_cast<int32_t*>(d + o_doc), reinterpret_cast<int64_t*>(d + o_row),
-                     reinterpret_cast<float*>(d + o_dist), reinterpret_cast<int32_t*>(d + o_cnt), nullptr);
-    if (rc) return rc;
+    auto run = [&](const float* qs, int n, const vsr_filter* const* fs, bool screening) -> int {
+        int r = search_impl(c, qs, nullptr, n, dim, k, metric, fs, reinterpret_cast<int64_t*>(d + o_blk),
+                            reinterpret_cast<int32_t*>(d + o_doc), reinterpret_cast<int64_t*>(d + o_row),
+                            reinterpret_cast<float*>(d + o_dist), reinterpret_cast<int32_t*>(d + o_cnt), nullptr, screening);
+        if (r) return r;
+        HIPCHK(hipMemcpyAsync(ctx->h_out.p, d, total, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return VSR_OK;
+    };
+    if ((rc = run(queries, nq, filters, true))) return rc;
     char* h = ctx->h_out.as<char>();
-    HIPCHK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(out_blk, h + o_blk, nk * 8);
     if (out_row) memcpy(out_row, h + o_row, nk * 8);
     if (out_doc) memcpy(out_doc, h + o_doc, nk * 4);
     memcpy(out_dist, h + o_dist, nk * 4);
     memcpy(out_cnt, h + o_cnt, (size_t) nq * 4);
+
+    // K2 screening flags: re-run the (rare) flagged queries on the exact scan path
+    std::vector<int32_t> flags((size_t) nq, 0);
+    HIPCHK(hipMemcpy(flags.data(), ctx->d_flags.p, (size_t) nq * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int> redo;
+    for (int i = 0; i < nq; ++i)
+        if (flags[(size_t) i]) redo.push_back(i);
+    if (!redo.empty()) {
+        ctx->flagged_seen += (int64_t) redo.size();
+        std::vector<float> q2(redo.size() * (size_t) dim);
+        std::vector<const vsr_filter*> f2(redo.size(), nullptr);
+        for (size_t j = 0; j < redo.size(); ++j) {
+            memcpy(&q2[j * (size_t) dim], queries + (size_t) redo[j] * dim, (size_t) dim * sizeof(float));
+            if (filters) f2[j] = filters[redo[j]];
+        }
+        if ((rc = run(q2.data(), (int) redo.size(), f2.data(), false))) return rc;
+        for (size_t j = 0; j < redo.size(); ++j) {
+            const size_t src = j * (size_t) k, dst = (size_t) redo[j] * k;
+            memcpy(out_blk + dst, reinterpret_cast<int64_t*>(h + o_blk) + src, (size_t) k * 8);
+            if (out_row) memcpy(out_row + dst, reinterpret_cast<int64_t*>(h + o_row) + src, (size_t) k * 8);
+            if (out_doc) memcpy(out_doc + dst, reinterpret_cast<int32_t*>(h + o_doc) + src, (size_t) k * 4);
+            memcpy(out_dist + dst, reinterpret_cast<float*>(h + o_dist) + src, (size_t) k * 4);
+            out_cnt[redo[j]] = reinterpret_cast<int32_t*>(h + o_cnt)[j];
+        }
+    }
+    return VSR_OK;
+}
+
+extern "C" int vsr_set_screening(vsr_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_set_screening: ctx is NULL");
+    ctx->screening = enable != 0;
+    return VSR_OK;
+}
+
+extern "C" int vsr_screening_check(vsr_ctx* ctx, int64_t* flagged_total, int32_t* flags_last_call, int nq)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_screening_check: ctx is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int32_t total = 0;
+    HIPCHK(hipMemcpy(&total, ctx->d_flag_total, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (flagged_total) *flagged_total = total;
+    if (flags_last_call && nq > 0) {
+        if (!ctx->d_flags.p || ctx->d_flags.cap < (size_t) nq * sizeof(int32_t))
+            memset(flags_last_call, 0, (size_t) nq * sizeof(int32_t));
+        else
+            HIPCHK(hipMemcpy(flags_last_call, ctx->d_flags.p, (size_t) nq * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return VSR_OK;
 }
 

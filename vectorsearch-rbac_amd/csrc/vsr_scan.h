@@ -151,9 +151,9 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
     const uint32_t q_count = grp.q_count;
     const uint32_t n_sub = (q_count + QI - 1) / QI;                           // wave-uniform
     for (uint32_t qi = tid; qi < qmax; qi += SCAN_THREADS) {
-        ctrl[qi].tau = KEY_EMPTY;
-        ctrl[qi].count = 0;
         const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
+        ctrl[qi].count = 0;
         qnl[qi] = (METRIC == M_COSINE) ? p.q_norm2[slot] : 0.0f;
     }
     if (tid < 4) flags[tid] = 0;
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
     const bool own = (l % D) == 0;
     const int row_own = (l / D) * G + g;
     const uint32_t trigger = cap - S::SLACK;
-    const uint32_t iters = (t1 - t0 + SCAN_WAVES - 1) / SCAN_WAVES;
+    const uint32_t ss = p.sample_stride;                                       // sample pass: every ss-th tile
+    const uint32_t iters = ((t1 - t0 + ss - 1) / ss + SCAN_WAVES - 1) / SCAN_WAVES;
 
     // issue the loads of tile t (no waits): descriptor, permission bits, row chunks
     auto fetch = [&](uint32_t t, TileRegs<R, CC>& tr) {
@@ -212,15 +213,15 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
     TileRegs<R, CC> cur;
 #if VSR_PREFETCH
     TileRegs<R, CC> nxt;
-    fetch(t0 + wave, cur);
+    fetch(t0 + wave * ss, cur);
 #endif
     uint32_t round = 0;
     for (uint32_t it = 0; it < iters; ++it) {
 #if VSR_PREFETCH
-        if (it + 1 < iters) fetch(t0 + (it + 1) * SCAN_WAVES + wave, nxt);     // prefetch the next tile
+        if (it + 1 < iters) fetch(t0 + ((it + 1) * SCAN_WAVES + wave) * ss, nxt);   // prefetch the next tile
         else nxt.mask = 0;
 #else
-        fetch(t0 + it * SCAN_WAVES + wave, cur);
+        fetch(t0 + (it * SCAN_WAVES + wave) * ss, cur);
 #endif
 
         if (cur.mask) {                                                        // wave-uniform
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
             ++round;
             if (any) {
                 for (uint32_t qs = 0; qs < q_count; ++qs)
-                    topk_compact<SCAN_THREADS>(keys + (size_t) qs * cap, &ctrl[qs], k, tid, false);
+                    if (ctrl[qs].count > trigger)                              // same value in every thread
+                        topk_compact<SCAN_THREADS>(keys + (size_t) qs * cap, &ctrl[qs], k, tid, false);
             }
         }
 #if VSR_PREFETCH

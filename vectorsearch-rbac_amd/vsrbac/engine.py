@@ -70,6 +70,17 @@ class Context:
     def stats_reset(self):
         check(self._lib.vsr_stats_reset(self._h))
 
+    def set_screening(self, enable=True):
+        """Allow the MFMA screening + exact re-rank path (K2/K5r) for shared passes."""
+        check(self._lib.vsr_set_screening(self._h, int(bool(enable))))
+
+    def screening_check(self, nq=0):
+        """(flagged queries since open, flags of the last vsr_search_device call).  Synchronises."""
+        total = C.c_int64()
+        flags = np.zeros(max(nq, 1), dtype=np.int32)
+        check(self._lib.vsr_screening_check(self._h, C.byref(total), _ptr(flags) if nq else None, int(nq)))
+        return total.value, flags[:nq]
+
     def tune(self, block_budget=-1, min_rows_per_block=0, max_queries_per_pass=0):
         check(self._lib.vsr_tune(self._h, block_budget, min_rows_per_block, max_queries_per_pass))
 
