@@ -71,11 +71,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # rehearsal on a 1-GPU box only: VSR_BENCH_REHEARSAL=1 puts every rank on GPU 0 and exchanges through gloo
+    rehearsal = os.environ.get("VSR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n, dim, k, nq = args.rows, args.dim, args.k, args.queries
     lo, hi = shard_bounds(n, world, rank, align=100)  # keep documents (100 rows) whole per shard
@@ -112,15 +119,23 @@ def main():
     def step():
         corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
                              ptr(d_cnt), ptr(d_keys))
-        if world > 1:
+        if world > 1 and rehearsal:
+            for g, d in ((g_keys, d_keys), (g_blk, d_blk), (g_doc, d_doc), (g_dist, d_dist)):
+                torch.cuda.synchronize()
+                hg = torch.empty(g.shape, dtype=g.dtype)
+                dist.all_gather_into_tensor(hg, d.cpu())
+                g.copy_(hg)
+        elif world > 1:
             dist.all_gather_into_tensor(g_keys, d_keys)
             dist.all_gather_into_tensor(g_blk, d_blk)
             dist.all_gather_into_tensor(g_doc, d_doc)
             dist.all_gather_into_tensor(g_dist, d_dist)
+        if world > 1:
             ctx.merge_topk_device(ptr(g_keys), ptr(g_blk), ptr(g_doc), ptr(g_dist), world, nq, k,
                                   ptr(m_blk), ptr(m_doc), ptr(m_dist), ptr(m_keys), ptr(m_cnt))
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -139,7 +154,11 @@ def main():
     ctx.profiling(False)
     flagged_total, _ = ctx.screening_check(0)         # K2 / seeding exactness flags over the whole run (expect 0)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        ft = torch.tensor([flagged_total], dtype=torch.int64, device=dev if not rehearsal else "cpu")
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        flagged_total = int(ft.item())
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if not rehearsal else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -212,6 +231,23 @@ def main():
                       f"cores (oracle built with pgvector's flags)",
         }
         out["parity_spot_check"] = {"queries": int(m), "ids_and_distances_identical": ok}
+    if rank == 0 and world > 1 and os.environ.get("VSR_BENCH_VERIFY") == "1":
+        # rehearsal check: the merged multi-rank result of a few queries against the oracle on the full corpus
+        from oracle.oracle import Oracle
+        orc = Oracle("pgflags")
+        xf, blkf, docf = sift_like_corpus(n, dim, seed=args.seed)
+        m = 8
+        ranges = [[((d - 1) * 100, 100) for d in rbac.visible_docs(int(u)).astype(np.int64)] for u in quser[:m]]
+        rows_o, dist_o, _ = orc.search_ranges("l2", xf, qvec[:m], k, ranges, docf, blkf)
+        ok = bool((m_blk[:m].cpu().numpy() == blkf[rows_o]).all() and
+                  (m_dist[:m].cpu().numpy() == dist_o.astype(np.float32)).all())
+        out["multi_rank_parity"] = {"queries": m, "ids_and_distances_identical": ok}
+        if not ok:
+            got_b, got_d = m_blk[:m].cpu().numpy(), m_dist[:m].cpu().numpy()
+            bad = np.argwhere(got_b != blkf[rows_o])
+            print("multi-rank mismatch at", bad[:5].tolist(), "got", got_b[0, :5].tolist(), got_d[0, :5].tolist(),
+                  "want", blkf[rows_o][0, :5].tolist(), dist_o[0, :5].tolist(), "counts", m_cnt[:m].cpu().tolist(),
+                  file=sys.stderr)
     if rank == 0:
         print(json.dumps(out), flush=True)
     corpus.free()

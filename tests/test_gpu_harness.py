@@ -83,8 +83,9 @@ def test_search_functions_match_oracle(ctx, oracle, world):
     dep.close()
 
 
+@pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("parts", [2, 3, 8])
-def test_sharded_merge_equals_single_gpu(ctx, oracle, world, parts):
+def test_sharded_merge_equals_single_gpu(ctx, oracle, world, parts, shared):
     """Row-range shards with row_offset, per-shard vsr_search_device, stacked like an all-gather, merged with
     vsr_merge_topk_device: must equal the unsharded search and the oracle (multi-GPU path on one GPU)."""
     import torch
@@ -95,6 +96,8 @@ def test_sharded_merge_equals_single_gpu(ctx, oracle, world, parts):
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(23)
     users = rng.integers(1, fx["num_users"] + 1, nq)
+    if shared:                                # all queries of one user: one shared pass per shard (K2 / K1m path)
+        users[:] = users[0]
     q = x[rng.integers(0, n, nq)]
     d_q = torch.from_numpy(q).to(dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr())

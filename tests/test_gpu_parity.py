@@ -133,6 +133,33 @@ def test_ties_follow_doc_block_order(ctx, oracle):
     corpus.free()
 
 
+def test_screening_gap_inside_error_bound_falls_back_to_exact(ctx, oracle):
+    """Shared passes run on the matrix cores (K2: MFMA screening keeps 2k candidates, K5r re-ranks exactly).  When the
+    2k-th candidate ties with the k-th result the re-rank cannot prove exactness: the query must be flagged and re-run
+    on the exact path, and the answer must still follow the (distance, document_id, block_id) order."""
+    rng = np.random.default_rng(12)
+    base = sift_like(rng, 8)
+    x = np.repeat(base, 300, axis=0)                     # every vector 300 times: ties far beyond 2k = 200
+    x = x[rng.permutation(x.shape[0])]
+    n = x.shape[0]
+    blk = (rng.permutation(n) + 1).astype(np.int64)
+    doc = rng.integers(1, 20, n).astype(np.int32)
+    corpus = ctx.load_corpus(x, blk, doc)
+    before, _ = ctx.screening_check(0)
+    res = corpus.search(base[:6], 100, "l2")             # 6 unfiltered queries share one pass
+    after, _ = ctx.screening_check(0)
+    for i in range(6):
+        _expect_exact(oracle, res, i, "l2", x, base[i], 100, doc, blk)
+    assert after > before, "the tie-saturated queries should have been flagged by the re-rank"
+    # with screening disabled the same call never flags
+    ctx.set_screening(False)
+    res2 = corpus.search(base[:6], 100, "l2")
+    ctx.set_screening(True)
+    assert ctx.screening_check(0)[0] == after
+    np.testing.assert_array_equal(res2.rows, res.rows)
+    corpus.free()
+
+
 # ---------------------------------------------------------------------------------------------
 # RBAC: fixtures produced by the reference's generators (tests/golden/make_rbac_fixture.py)
 # ---------------------------------------------------------------------------------------------

@@ -76,9 +76,27 @@ class GpuShardEngine:
                "dist": torch.empty((nq, k), dtype=torch.float32, device=self.device),
                "keys": torch.empty((nq, k), dtype=torch.int64, device=self.device),
                "counts": torch.empty((nq,), dtype=torch.int32, device=self.device)}
-        self._keep = self.corpus.search_device(self._p(q), nq, k, metric, filters, self._p(out["block"]),
-                                               self._p(out["doc"]), None, self._p(out["dist"]),
-                                               self._p(out["counts"]), self._p(out["keys"]))
+        args = (self._p(out["block"]), self._p(out["doc"]), None, self._p(out["dist"]), self._p(out["counts"]),
+                self._p(out["keys"]))
+        self._keep = self.corpus.search_device(self._p(q), nq, k, metric, filters, *args)
+        # K2 screening / seeded thresholds: queries whose exactness could not be proven are re-run on the exact path
+        _, flags = self.ctx.screening_check(nq)
+        redo = np.flatnonzero(flags)
+        if redo.size:
+            self.ctx.set_screening(False)
+            try:
+                idx = torch.from_numpy(redo).to(self.device)
+                sub = {n: torch.empty((redo.size,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+                       for n, t in out.items()}
+                fl = None if filters is None else [filters[i] for i in redo] if not hasattr(filters, "_h") else filters
+                self._keep = self.corpus.search_device(self._p(q[idx].contiguous()), int(redo.size), k, metric, fl,
+                                                       self._p(sub["block"]), self._p(sub["doc"]), None,
+                                                       self._p(sub["dist"]), self._p(sub["counts"]), self._p(sub["keys"]))
+                self.ctx.synchronize()
+                for n in out:
+                    out[n][idx] = sub[n]
+            finally:
+                self.ctx.set_screening(True)
         return out
 
     def finalize(self, local):
