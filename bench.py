@@ -102,37 +102,37 @@ def main():
     t_load = time.time() - t0 - t_gen
 
     d_q = torch.from_numpy(qvec).to(dev)
-    d_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    d_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    # one packed result record per rank {keys u64, block i64, doc i32, dist f32}[nq][k]: a single all-gather moves it
+    rec = ctx.packed_result_bytes(nq, k)
+    d_pack = torch.empty((rec,), dtype=torch.uint8, device=dev)
+    nk = nq * k
+    d_keys = d_pack[0:nk * 8].view(torch.int64).view(nq, k)            # raw u64 ordering keys
+    d_blk = d_pack[nk * 8:nk * 16].view(torch.int64).view(nq, k)
+    d_doc = d_pack[nk * 16:nk * 20].view(torch.int32).view(nq, k)
+    d_dist = d_pack[nk * 20:nk * 24].view(torch.float32).view(nq, k)
     d_row = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    d_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
     d_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
-    d_keys = torch.empty((nq, k), dtype=torch.int64, device=dev)      # raw u64 ordering keys
     if world > 1:
-        g_keys = torch.empty((world * nq, k), dtype=torch.int64, device=dev)      # [world][nq][k]
-        g_blk = torch.empty((world * nq, k), dtype=torch.int64, device=dev)
-        g_doc = torch.empty((world * nq, k), dtype=torch.int32, device=dev)
-        g_dist = torch.empty((world * nq, k), dtype=torch.float32, device=dev)
-        m_blk, m_doc, m_dist = torch.empty_like(d_blk), torch.empty_like(d_doc), torch.empty_like(d_dist)
-        m_cnt, m_keys = torch.empty_like(d_cnt), torch.empty_like(d_keys)
+        g_pack = torch.empty((world * rec,), dtype=torch.uint8, device=dev)       # [world] packed records
+        m_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        m_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        m_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        m_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+        m_keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
 
     def step():
         corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
                              ptr(d_cnt), ptr(d_keys))
         if world > 1 and rehearsal:
-            for g, d in ((g_keys, d_keys), (g_blk, d_blk), (g_doc, d_doc), (g_dist, d_dist)):
-                torch.cuda.synchronize()
-                hg = torch.empty(g.shape, dtype=g.dtype)
-                dist.all_gather_into_tensor(hg, d.cpu())
-                g.copy_(hg)
+            torch.cuda.synchronize()
+            hg = torch.empty((world * rec,), dtype=torch.uint8)
+            dist.all_gather_into_tensor(hg, d_pack.cpu())
+            g_pack.copy_(hg)
         elif world > 1:
-            dist.all_gather_into_tensor(g_keys, d_keys)
-            dist.all_gather_into_tensor(g_blk, d_blk)
-            dist.all_gather_into_tensor(g_doc, d_doc)
-            dist.all_gather_into_tensor(g_dist, d_dist)
+            dist.all_gather_into_tensor(g_pack, d_pack)           # RCCL over xGMI: nq*k*24 bytes per rank
         if world > 1:
-            ctx.merge_topk_device(ptr(g_keys), ptr(g_blk), ptr(g_doc), ptr(g_dist), world, nq, k,
-                                  ptr(m_blk), ptr(m_doc), ptr(m_dist), ptr(m_keys), ptr(m_cnt))
+            ctx.merge_topk_packed_device(ptr(g_pack), world, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist), ptr(m_keys),
+                                         ptr(m_cnt))
 
     def barrier():
         torch.cuda.synchronize()

@@ -149,6 +149,14 @@ int vsr_merge_topk_device(vsr_ctx* ctx, const uint64_t* d_keys, const int64_t* d
                           int64_t* d_out_block_ids, int32_t* d_out_doc_ids, float* d_out_dist,
                           uint64_t* d_out_keys, int32_t* d_out_counts);
 
+/* Same merge for PACKED per-shard results: one record per shard of vsr_packed_result_bytes(nq, k) = nq*k*24 bytes,
+ * laid out {keys u64[nq][k], block_ids i64[nq][k], doc_ids i32[nq][k], dist f32[nq][k]} — i.e. the four output
+ * pointers of vsr_search_device aimed into one buffer — so that ONE all-gather moves a rank's whole result. */
+int64_t vsr_packed_result_bytes(int nq, int k);
+int vsr_merge_topk_packed_device(vsr_ctx* ctx, const void* d_packed, int n_parts, int nq, int k,
+                                 int64_t* d_out_block_ids, int32_t* d_out_doc_ids, float* d_out_dist,
+                                 uint64_t* d_out_keys, int32_t* d_out_counts);
+
 /* operator value for n explicit pairs a[i] (dim floats) vs b[i] (or one shared b when b_broadcast != 0):
  * what `SELECT a <-> b` evaluates per row (vector.c:568-578 etc.), batched.  Host pointers. */
 int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, const float* b, int64_t n_pairs,

@@ -121,8 +121,24 @@ def test_sharded_merge_equals_single_gpu(ctx, oracle, world, parts, shared):
     o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
     ctx.merge_topk_device(p(g["keys"]), p(g["block"]), p(g["doc"]), p(g["dist"]), parts, nq, k,
                           p(o_blk), p(o_doc), p(o_dist), None, p(o_cnt))
+    # the same merge from packed per-shard records (what a single all-gather delivers)
+    ctx.synchronize()                                   # the library runs on its own stream here
+    rec = ctx.packed_result_bytes(nq, k)
+    packed = torch.empty((parts * rec,), dtype=torch.uint8, device=dev)
+    nk = nq * k
+    for r in range(parts):
+        base = r * rec
+        packed[base:base + nk * 8] = g["keys"][r].contiguous().view(torch.uint8).flatten()
+        packed[base + nk * 8:base + nk * 16] = g["block"][r].contiguous().view(torch.uint8).flatten()
+        packed[base + nk * 16:base + nk * 20] = g["doc"][r].contiguous().view(torch.uint8).flatten()
+        packed[base + nk * 20:base + nk * 24] = g["dist"][r].contiguous().view(torch.uint8).flatten()
+    p_blk, p_doc, p_dist, p_cnt = (torch.empty_like(o_blk), torch.empty_like(o_doc), torch.empty_like(o_dist),
+                                   torch.empty_like(o_cnt))
+    torch.cuda.synchronize()
+    ctx.merge_topk_packed_device(p(packed), parts, nq, k, p(p_blk), p(p_doc), p(p_dist), None, p(p_cnt))
     ctx.synchronize()
     torch.cuda.synchronize()
+    assert torch.equal(p_blk, o_blk) and torch.equal(p_doc, o_doc) and torch.equal(p_dist, o_dist) and torch.equal(p_cnt, o_cnt)
     for i in range(nq):
         mask = oracle.user_row_mask(int(users[i]), fx["user_roles"], fx["permissions"], doc)
         idx, d = oracle.filtered_topk("l2", x, q[i], k, doc, blk, mask)

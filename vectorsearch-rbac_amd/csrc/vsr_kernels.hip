@@ -207,9 +207,12 @@ hipError_t launch_select(const SelectParams& p, uint32_t n_queries, hipStream_t 
 __global__ __launch_bounds__(256) void merge_lists_kernel(const uint64_t* keys, const int64_t* blocks,
                                                           const int32_t* docs, const float* dist,
                                                           uint32_t n_parts, uint32_t n_queries, uint32_t k,
-                                                          uint32_t np2, int64_t* out_block, int32_t* out_doc,
-                                                          float* out_dist, uint64_t* out_keys, int32_t* out_count)
+                                                          uint32_t np2, size_t part_stride, int64_t* out_block,
+                                                          int32_t* out_doc, float* out_dist, uint64_t* out_keys,
+                                                          int32_t* out_count)
 {
+    // part_stride == 0: four arrays of layout [n_parts][nq][k]; else every part is one packed record
+    // {keys[nq][k], blocks[nq][k], docs[nq][k], dist[nq][k]} and part p starts part_stride bytes after part p-1
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* skey = reinterpret_cast<uint64_t*>(smem);          // [np2]
     uint32_t* spos = reinterpret_cast<uint32_t*>(skey + np2);    // [np2]
@@ -221,8 +224,13 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const uint64_t* keys, 
         uint32_t pos = 0;
         if (i < total) {
             const uint32_t part = i / k, j = i % k;
-            pos = (part * n_queries + q) * k + j;
-            key = keys[pos];
+            if (part_stride) {
+                pos = i;                                     // position = (part, j); resolved again when reading
+                key = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(keys) + part * part_stride)[q * k + j];
+            } else {
+                pos = (part * n_queries + q) * k + j;
+                key = keys[pos];
+            }
         }
         skey[i] = key;
         spos[i] = pos;
@@ -248,9 +256,17 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const uint64_t* keys, 
         const uint64_t key = i < np2 ? skey[i] : KEY_EMPTY;
         if (key != KEY_EMPTY) {
             const uint32_t pos = spos[i];
-            out_block[o] = blocks[pos];
-            out_doc[o] = docs[pos];
-            out_dist[o] = dist[pos];
+            if (part_stride) {
+                const size_t off = (size_t) (pos / k) * part_stride;
+                const uint32_t e = q * k + pos % k;
+                out_block[o] = reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(blocks) + off)[e];
+                out_doc[o] = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(docs) + off)[e];
+                out_dist[o] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(dist) + off)[e];
+            } else {
+                out_block[o] = blocks[pos];
+                out_doc[o] = docs[pos];
+                out_dist[o] = dist[pos];
+            }
             if (out_keys) out_keys[o] = key;
         } else {
             out_block[o] = -1;
@@ -273,7 +289,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const uint64_t* keys, 
 }
 
 hipError_t launch_merge_lists(const uint64_t* keys, const int64_t* blocks, const int32_t* docs, const float* dist,
-                              uint32_t n_parts, uint32_t n_queries, uint32_t k, int64_t* out_block,
+                              uint32_t n_parts, uint32_t n_queries, uint32_t k, size_t part_stride, int64_t* out_block,
                               int32_t* out_doc, float* out_dist, uint64_t* out_keys, int32_t* out_count,
                               hipStream_t s)
 {
@@ -287,7 +303,7 @@ hipError_t launch_merge_lists(const uint64_t* keys, const int64_t* blocks, const
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(merge_lists_kernel, dim3(n_queries), dim3(256), lds, s, keys, blocks, docs, dist, n_parts,
-                       n_queries, k, np2, out_block, out_doc, out_dist, out_keys, out_count);
+                       n_queries, k, np2, part_stride, out_block, out_doc, out_dist, out_keys, out_count);
     return hipGetLastError();
 }
 

@@ -886,7 +886,8 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
     plan.selq.resize((size_t) nq);
     for (auto& p : passes) {
         int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows - 1) / total_rows;
-        nb = std::min<int64_t>(nb, std::max<int64_t>(1, p.rows / ctx->min_rows_per_block));
+        const int64_t min_rows = p.q_count > 1 ? std::max<int64_t>(ctx->min_rows_per_block, 2048) : ctx->min_rows_per_block;
+        nb = std::min<int64_t>(nb, std::max<int64_t>(1, p.rows / min_rows));   // shared passes need rows to prune on
         nb = std::min<int64_t>(nb, std::max<uint32_t>(1, p.n_tiles));
         nb = std::max<int64_t>(nb, 1);
         const bool empty = p.n_tiles == 0 || p.rows == 0;
@@ -1317,8 +1318,30 @@ extern "C" int vsr_merge_topk_device(vsr_ctx* ctx, const uint64_t* d_keys, const
     if (nq == 0) return VSR_OK;
     if ((int64_t) n_parts * k > 8192) return fail(VSR_ERR_UNSUPPORTED, "vsr_merge_topk_device: n_parts * k > 8192");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(launch_merge_lists(d_keys, d_blk, d_doc, d_dist, (uint32_t) n_parts, (uint32_t) nq, (uint32_t) k, o_blk,
+    HIPCHK(launch_merge_lists(d_keys, d_blk, d_doc, d_dist, (uint32_t) n_parts, (uint32_t) nq, (uint32_t) k, 0, o_blk,
                               o_doc, o_dist, o_keys, o_cnt, ctx->stream));
+    return VSR_OK;
+}
+
+extern "C" int64_t vsr_packed_result_bytes(int nq, int k)
+{
+    return nq < 0 || k < 1 ? 0 : (int64_t) nq * k * 24;
+}
+
+extern "C" int vsr_merge_topk_packed_device(vsr_ctx* ctx, const void* d_packed, int n_parts, int nq, int k,
+                                            int64_t* o_blk, int32_t* o_doc, float* o_dist, uint64_t* o_keys, int32_t* o_cnt)
+{
+    if (!ctx || !d_packed || !o_blk || !o_doc || !o_dist || !o_cnt) return fail(VSR_ERR_INVALID, "vsr_merge_topk_packed_device: NULL argument");
+    if (n_parts < 1 || nq < 0 || k < 1) return fail(VSR_ERR_INVALID, "vsr_merge_topk_packed_device: bad sizes");
+    if (nq == 0) return VSR_OK;
+    if ((int64_t) n_parts * k > 8192) return fail(VSR_ERR_UNSUPPORTED, "vsr_merge_topk_packed_device: n_parts * k > 8192");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nk = (size_t) nq * k;
+    const char* base = reinterpret_cast<const char*>(d_packed);
+    HIPCHK(launch_merge_lists(reinterpret_cast<const uint64_t*>(base), reinterpret_cast<const int64_t*>(base + nk * 8),
+                              reinterpret_cast<const int32_t*>(base + nk * 16), reinterpret_cast<const float*>(base + nk * 20),
+                              (uint32_t) n_parts, (uint32_t) nq, (uint32_t) k, nk * 24, o_blk, o_doc, o_dist, o_keys, o_cnt,
+                              ctx->stream));
     return VSR_OK;
 }
 

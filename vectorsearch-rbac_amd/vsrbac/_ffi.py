@@ -49,6 +49,8 @@ SYMBOLS = {
     "vsr_set_screening": (_i, [_vp, _i]),
     "vsr_screening_check": (_i, [_vp, C.POINTER(_i64), _vp, _i]),
     "vsr_merge_topk_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vsr_packed_result_bytes": (_i64, [_i, _i]),
+    "vsr_merge_topk_packed_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "vsr_pair_distances": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "vsr_profiling": (_i, [_vp, _i]),
     "vsr_stats_get": (_i, [_vp, C.POINTER(Stats)]),

@@ -106,6 +106,15 @@ class Context:
                                               out_block, out_doc, out_dist, out_keys, out_counts))
 
 
+    def packed_result_bytes(self, nq, k):
+        return self._lib.vsr_packed_result_bytes(int(nq), int(k))
+
+    def merge_topk_packed_device(self, packed, n_parts, nq, k, out_block, out_doc, out_dist, out_keys, out_counts):
+        """`packed`: device pointer to n_parts records of packed_result_bytes(nq, k) bytes (one all-gather)."""
+        check(self._lib.vsr_merge_topk_packed_device(self._h, packed, n_parts, nq, k, out_block, out_doc, out_dist,
+                                                     out_keys, out_counts))
+
+
 class Filter:
     def __init__(self, corpus, handle, owned):
         self.corpus = corpus

@@ -45,6 +45,11 @@ class ShardedSearcher:
         if self.world == 1:
             return self.engine.finalize(local)
         import torch
+        if "pack" in local:                     # one collective: the rank's whole result as one packed record
+            t = local["pack"]
+            g = torch.empty((self.world * t.shape[0],), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(g, t, group=self.group)
+            return self.engine.merge_packed(g, local["keys"].shape[0], k)
         gathered = {}
         for name in ("keys", "block", "doc", "dist"):
             t = local[name].contiguous()
@@ -71,10 +76,12 @@ class GpuShardEngine:
         q = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries, np.float32))
         q = q.to(self.device, torch.float32).contiguous()
         nq = q.shape[0]
-        out = {"block": torch.empty((nq, k), dtype=torch.int64, device=self.device),
-               "doc": torch.empty((nq, k), dtype=torch.int32, device=self.device),
-               "dist": torch.empty((nq, k), dtype=torch.float32, device=self.device),
-               "keys": torch.empty((nq, k), dtype=torch.int64, device=self.device),
+        nk = nq * k
+        pack = torch.empty((self.ctx.packed_result_bytes(nq, k),), dtype=torch.uint8, device=self.device)
+        out = {"keys": pack[0:nk * 8].view(torch.int64).view(nq, k),
+               "block": pack[nk * 8:nk * 16].view(torch.int64).view(nq, k),
+               "doc": pack[nk * 16:nk * 20].view(torch.int32).view(nq, k),
+               "dist": pack[nk * 20:nk * 24].view(torch.float32).view(nq, k),
                "counts": torch.empty((nq,), dtype=torch.int32, device=self.device)}
         args = (self._p(out["block"]), self._p(out["doc"]), None, self._p(out["dist"]), self._p(out["counts"]),
                 self._p(out["keys"]))
@@ -87,7 +94,7 @@ class GpuShardEngine:
             try:
                 idx = torch.from_numpy(redo).to(self.device)
                 sub = {n: torch.empty((redo.size,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
-                       for n, t in out.items()}
+                       for n, t in out.items()}          # (pack is attached after the fallback)
                 fl = None if filters is None else [filters[i] for i in redo] if not hasattr(filters, "_h") else filters
                 self._keep = self.corpus.search_device(self._p(q[idx].contiguous()), int(redo.size), k, metric, fl,
                                                        self._p(sub["block"]), self._p(sub["doc"]), None,
@@ -97,10 +104,22 @@ class GpuShardEngine:
                     out[n][idx] = sub[n]
             finally:
                 self.ctx.set_screening(True)
+        out["pack"] = pack
         return out
 
     def finalize(self, local):
         return local["block"], local["doc"], local["dist"], local["counts"]
+
+    def merge_packed(self, g_pack, nq, k):
+        torch = self.torch
+        world = g_pack.numel() // self.ctx.packed_result_bytes(nq, k)
+        blk = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        doc = torch.empty((nq, k), dtype=torch.int32, device=self.device)
+        dist = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        cnt = torch.empty((nq,), dtype=torch.int32, device=self.device)
+        self.ctx.merge_topk_packed_device(self._p(g_pack), world, nq, k, self._p(blk), self._p(doc), self._p(dist),
+                                          None, self._p(cnt))
+        return blk, doc, dist, cnt
 
     def merge(self, g, k):
         torch = self.torch
