@@ -112,7 +112,9 @@ __device__ __forceinline__ float output_distance(int metric, float v)
     return metric == M_L2 ? (float) sqrt((double) v) : v;
 }
 
-__global__ __launch_bounds__(SELECT_THREADS) void select_kernel(const SelectParams p)
+// NT = 1024 for long candidate streams, 256 for short ones (cheaper barriers, 8 workgroups per CU)
+template <int NT>
+__global__ __launch_bounds__(NT) void select_kernel(const SelectParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -128,22 +130,22 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(const SelectPara
 
     const uint64_t* src = p.partial + (size_t) sq.partial_begin * p.kp;
     const uint64_t total = (uint64_t) sq.n_lists * p.kp;
-    const uint32_t trigger = cap - SELECT_THREADS;
+    const uint32_t trigger = cap - NT;
     uint64_t next = (uint64_t) tid < total ? src[tid] : KEY_EMPTY;            // one key ahead of the loop
-    for (uint64_t base = 0; base < total; base += SELECT_THREADS) {
+    for (uint64_t base = 0; base < total; base += NT) {
         const uint64_t key = next;
-        const uint64_t in = base + SELECT_THREADS + tid;
+        const uint64_t in = base + NT + tid;
         next = in < total ? src[in] : KEY_EMPTY;
         const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl->tau);
         topk_append(keys, ctrl, key < tau, key);            // KEY_EMPTY never passes (tau <= KEY_EMPTY)
-        if (base + SELECT_THREADS < total) {
+        if (base + NT < total) {
             __syncthreads();                                 // every append of this round is counted
-            if (ctrl->count > trigger) topk_compact<SELECT_THREADS>(keys, ctrl, k, tid, false);
+            if (ctrl->count > trigger) topk_compact<NT>(keys, ctrl, k, tid, false);
             else __syncthreads();                            // nobody appends before all have read count
         }
     }
     __syncthreads();
-    topk_compact<SELECT_THREADS>(keys, ctrl, k, tid, true);
+    topk_compact<NT>(keys, ctrl, k, tid, true);
 
     if (sq.dst_list == SEL_SEED) {
         // seed threshold from the sample pass: every row ranking at or before the k-th sampled candidate stays
@@ -154,13 +156,13 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(const SelectPara
     if (sq.dst_list != SEL_FINAL) {                          // level 1 of a two-level merge
         const uint32_t n = ctrl->count < k ? ctrl->count : k;
         uint64_t* dst = p.partial + (size_t) sq.dst_list * p.kp;
-        for (uint32_t i = tid; i < p.kp; i += SELECT_THREADS) dst[i] = i < n ? keys[i] : KEY_EMPTY;
+        for (uint32_t i = tid; i < p.kp; i += NT) dst[i] = i < n ? keys[i] : KEY_EMPTY;
         return;
     }
 
     const uint32_t m = ctrl->count < k ? ctrl->count : k;
     const size_t out = (size_t) sq.out_slot * k;
-    for (uint32_t i = tid; i < k; i += SELECT_THREADS) {
+    for (uint32_t i = tid; i < k; i += NT) {
         if (i < m) {
             const uint64_t key = keys[i];
             const uint32_t row = (uint32_t) key;
@@ -187,16 +189,26 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(const SelectPara
     }
 }
 
-hipError_t launch_select(const SelectParams& p, uint32_t n_queries, hipStream_t s)
+hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s)
 {
     const size_t lds = (size_t) p.cap * sizeof(uint64_t) + sizeof(TopKCtrl);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(select_kernel, dim3(n_queries), dim3(SELECT_THREADS), lds, s, p);
-    return hipGetLastError();
+    auto launch = [&](auto kern, int nt) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(n_queries), dim3(nt), lds, s, p);
+        return hipGetLastError();
+    };
+    return threads == 256 ? launch(select_kernel<256>, 256) : launch(select_kernel<1024>, 1024);
+}
+
+uint32_t select_cap(uint32_t k, int threads)
+{
+    uint32_t cap = 512;
+    while (cap < 2 * k + (uint32_t) threads) cap <<= 1;
+    return cap;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -466,40 +478,56 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
     for (int m = 32; m >= 1; m >>= 1) qn_part += __shfl_xor(qn_part, m);
     const float qn = qn_part;
 
-    for (uint32_t c = wave; c < np2; c += 4) {
-        uint64_t out = KEY_EMPTY;
-        const uint64_t sk = c < p.kp ? list[c] : KEY_EMPTY;
-        if (sk != KEY_EMPTY) {                                             // wave-uniform
-            const uint32_t row = (uint32_t) sk;
-            const float4* x = p.rows + (size_t) row * p.stride4;
-            float s = 0.0f, nx = 0.0f;
-            for (uint32_t ch = lane; ch < p.stride4; ch += 64) {
-                const float4 a = x[ch], b = q[ch];
+    // half a wave per candidate (32 lanes x float4 = 128 floats per step), two candidates per half-wave in flight:
+    // four independent row gathers per wave hide the HBM/L2 latency of these scattered 512-byte reads
+    const int half = lane >> 5, hl = lane & 31;
+    for (uint32_t c0 = (uint32_t) wave * 4; c0 < np2; c0 += 16) {
+        uint64_t sk[2];
+        float s[2] = {0.f, 0.f}, nx[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t c = c0 + 2 * u + half;
+            sk[u] = c < p.kp ? list[c] : KEY_EMPTY;
+        }
+        for (uint32_t ch = hl; ch < p.stride4; ch += 32) {
+            const float4 b = q[ch];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (sk[u] == KEY_EMPTY) continue;
+                const float4 a = p.rows[(size_t) (uint32_t) sk[u] * p.stride4 + ch];
                 if (p.metric == M_L2) {
                     const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-                    s = fmaf(d0, d0, s); s = fmaf(d1, d1, s); s = fmaf(d2, d2, s); s = fmaf(d3, d3, s);
+                    s[u] = fmaf(d0, d0, s[u]); s[u] = fmaf(d1, d1, s[u]); s[u] = fmaf(d2, d2, s[u]); s[u] = fmaf(d3, d3, s[u]);
                 } else {
-                    s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+                    s[u] = fmaf(a.x, b.x, s[u]); s[u] = fmaf(a.y, b.y, s[u]); s[u] = fmaf(a.z, b.z, s[u]); s[u] = fmaf(a.w, b.w, s[u]);
                     if (p.metric == M_COSINE) {
-                        nx = fmaf(a.x, a.x, nx); nx = fmaf(a.y, a.y, nx); nx = fmaf(a.z, a.z, nx); nx = fmaf(a.w, a.w, nx);
+                        nx[u] = fmaf(a.x, a.x, nx[u]); nx[u] = fmaf(a.y, a.y, nx[u]);
+                        nx[u] = fmaf(a.z, a.z, nx[u]); nx[u] = fmaf(a.w, a.w, nx[u]);
                     }
                 }
             }
-            for (int m = 32; m >= 1; m >>= 1) {
-                s += __shfl_xor(s, m);
-                nx += __shfl_xor(nx, m);
-            }
-            float v;
-            if (p.metric == M_L2) v = s;
-            else if (p.metric == M_IP) v = -s;
-            else {
-                double sim = (double) s / sqrt((double) nx * (double) qn);
-                if (sim > 1.0) sim = 1.0; else if (sim < -1.0) sim = -1.0;
-                v = (float) (1.0 - sim);
-            }
-            out = make_key(v, row);
         }
-        if (lane == 0) keys[c] = out;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            for (int m = 16; m >= 1; m >>= 1) {                            // within the half-wave
+                s[u] += __shfl_xor(s[u], m);
+                nx[u] += __shfl_xor(nx[u], m);
+            }
+            const uint32_t c = c0 + 2 * u + half;
+            uint64_t out = KEY_EMPTY;
+            if (sk[u] != KEY_EMPTY) {
+                float v;
+                if (p.metric == M_L2) v = s[u];
+                else if (p.metric == M_IP) v = -s[u];
+                else {
+                    double sim = (double) s[u] / sqrt((double) nx[u] * (double) qn);
+                    if (sim > 1.0) sim = 1.0; else if (sim < -1.0) sim = -1.0;
+                    v = (float) (1.0 - sim);
+                }
+                out = make_key(v, (uint32_t) sk[u]);
+            }
+            if (hl == 0 && c < np2) keys[c] = out;
+        }
     }
     __syncthreads();
     bitonic_sort_lds<256>(keys, np2, tid);

@@ -116,6 +116,7 @@ struct vsr_ctx {
     DevBuf d_tau;        // seeded thresholds (sample pass)
     bool   seeding = true;        // seed thresholds of big shared passes from a 1/32 sample pass
     int64_t seed_min_rows = 2000000;
+    int64_t seed_min_pass_rows = 16384;  // average rows per pass below which the warm-up it removes is too small to pay
     int32_t* d_flag_total = nullptr;   // running count of flagged queries (device)
     bool   screening = true;      // allow K2 (MFMA screening + exact re-rank) for shared passes
     int64_t flagged_seen = 0;
@@ -231,6 +232,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_NO_MQ"))) ctx->no_mq = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
+    if ((env = getenv("VSR_SEED_MIN_PASS"))) ctx->seed_min_pass_rows = atoll(env);
     if ((env = getenv("VSR_SEED_STRIDE"))) SEED_STRIDE = (uint32_t) std::max(2, atoi(env));
     if ((env = getenv("VSR_SEED_DIV"))) SEED_BLOCK_DIV = (uint32_t) std::max(1, atoi(env));
     if ((env = getenv("VSR_NO_SCREENING"))) ctx->screening = atoi(env) == 0;
@@ -1061,8 +1063,13 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     SelectParams sel;
     sel.partial = ctx->d_partial.as<uint64_t>();
     sel.kp = kp;
-    sel.cap = 2048;
-    while (sel.cap < (uint32_t) (2 * kp + SELECT_THREADS)) sel.cap <<= 1;
+    // short candidate streams (<= 16k keys per query) merge faster with small workgroups
+    uint32_t max_lists = 1;
+    for (auto& q : plan.selq) max_lists = std::max(max_lists, q.n_lists);
+    for (auto& q : plan.sel1) max_lists = std::max(max_lists, q.n_lists);
+    for (auto& q : plan.seedq) max_lists = std::max(max_lists, q.n_lists);
+    const int sel_threads = (uint64_t) max_lists * kp <= 16384 ? 256 : 1024;
+    sel.cap = select_cap(kp, sel_threads);
     sel.metric = metric;
     sel.row_offset = (uint32_t) c->row_offset;
     sel.block_ids = c->d_block;
@@ -1083,7 +1090,8 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     // query becomes the initial threshold of the main pass (all rows at or before it stay eligible; a query whose
     // seed turns out too tight is flagged by K5 / K5r and re-run unseeded) ----
     const bool seed = allow_screening && ctx->seeding && (plan.k2 || plan.mq) && plan.n_blocks > 0 &&
-                      plan.scan_rows >= ctx->seed_min_rows;
+                      plan.scan_rows >= ctx->seed_min_rows &&
+                      plan.scan_rows / (int64_t) std::max<size_t>(1, plan.groups.size()) >= ctx->seed_min_pass_rows;
     sp.sample_stride = 1;
     sp.tau_init = nullptr;
     if (seed) {
@@ -1112,7 +1120,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
         sel.k = std::min(m, kp);
         sel.tau_out = ctx->d_tau.as<uint64_t>();
         sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sd);
-        HIPCHK(launch_select(sel, (uint32_t) plan.seedq.size(), ctx->stream));
+        HIPCHK(launch_select(sel, (uint32_t) plan.seedq.size(), sel_threads, ctx->stream));
         if (a0) {
             HIPCHK(hipEventRecord(b1, ctx->stream));
             ctx->pending.push_back({a0, a1, 3});
@@ -1151,10 +1159,10 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     }
     if (!plan.sel1.empty()) {
         sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_s1);
-        HIPCHK(launch_select(sel, (uint32_t) plan.sel1.size(), ctx->stream));
+        HIPCHK(launch_select(sel, (uint32_t) plan.sel1.size(), sel_threads, ctx->stream));
     }
     sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
-    HIPCHK(launch_select(sel, (uint32_t) nq, ctx->stream));
+    HIPCHK(launch_select(sel, (uint32_t) nq, sel_threads, ctx->stream));
     if (plan.k2) {
         RerankParams rr;
         rr.lists = ctx->d_partial.as<uint64_t>() + (size_t) plan.rerank_base * kp;
