@@ -23,7 +23,7 @@ struct ScanGroup {
     const uint2*    tiles;         // (row_start, n_rows<=RW) list; nullptr => implicit tiles over [0, n_rows)
     const uint64_t* bitmap;        // per-row permission bits over internal row order; nullptr => none
     uint32_t        n_tiles;
-    uint32_t        q_begin;       // first query slot (queries of a group are contiguous)
+    uint32_t        q_begin;       // this pass's queries are slots q_slots[q_begin .. q_begin + q_count)
     uint32_t        q_count;       // 1..QB
     uint32_t        block_begin;   // first workgroup of this group in the launch
     uint32_t        n_blocks;
@@ -39,6 +39,7 @@ struct ScanParams {
     const float*     q_norm2;      // [n_slots]
     const ScanGroup* groups;
     uint32_t         n_groups;
+    const uint32_t*  q_slots;      // query slots of all passes, concatenated
     uint64_t*        partial;      // [n_partial][kp] keys, KEY_EMPTY padded
     uint32_t         kp;           // partial list length (>= k)
     uint32_t         k;
@@ -54,8 +55,8 @@ struct ScanParams {
 
 // Per query: which partial lists to merge and where to put the result.
 struct SelectQuery {
-    uint32_t partial_begin;
-    uint32_t n_lists;              // lists are partial_begin + j, j < n_lists
+    uint32_t ids_begin;            // the query's partial lists are list_ids[ids_begin + j], j < n_lists
+    uint32_t n_lists;
     uint32_t out_slot;             // output row in the result arrays (caller's query index)
     uint32_t dst_list;             // SEL_FINAL: write final results; SEL_SEED: write the seed threshold;
                                    // else: write the k best keys as partial list dst_list
@@ -72,6 +73,7 @@ struct SelectParams {
     int32_t*           flagged_total;
     int                seeded;
     uint64_t*          partial;
+    const uint32_t*    list_ids;       // partial list indices, per query a contiguous run
     const SelectQuery* queries;
     uint32_t           kp;
     uint32_t           k;

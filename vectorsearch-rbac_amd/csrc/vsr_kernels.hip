@@ -128,14 +128,19 @@ __global__ __launch_bounds__(NT) void select_kernel(const SelectParams p)
     }
     __syncthreads();
 
-    const uint64_t* src = p.partial + (size_t) sq.partial_begin * p.kp;
-    const uint64_t total = (uint64_t) sq.n_lists * p.kp;
+    const uint32_t* ids = p.list_ids + sq.ids_begin;
+    const uint32_t kp = p.kp;
+    const uint64_t total = (uint64_t) sq.n_lists * kp;
     const uint32_t trigger = cap - NT;
-    uint64_t next = (uint64_t) tid < total ? src[tid] : KEY_EMPTY;            // one key ahead of the loop
+    auto fetch = [&](uint64_t i) -> uint64_t {              // key i of the query's concatenated lists
+        if (i >= total) return KEY_EMPTY;
+        const uint32_t j = (uint32_t) (i / kp);
+        return p.partial[(size_t) ids[j] * kp + (uint32_t) (i - (uint64_t) j * kp)];
+    };
+    uint64_t next = fetch(tid);                              // one key ahead of the loop
     for (uint64_t base = 0; base < total; base += NT) {
         const uint64_t key = next;
-        const uint64_t in = base + NT + tid;
-        next = in < total ? src[in] : KEY_EMPTY;
+        next = fetch(base + NT + tid);
         const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl->tau);
         topk_append(keys, ctrl, key < tau, key);            // KEY_EMPTY never passes (tau <= KEY_EMPTY)
         if (base + NT < total) {
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(256) void gather_queries_kernel(const float* src, c
                                                              uint32_t dim, uint32_t qfloats, float* dst)
 {
     const uint32_t s = blockIdx.x;
-    const float* q = src + (size_t) slot_query[s] * dim;
+    const float* q = src + (size_t) (slot_query ? slot_query[s] : s) * dim;
     for (uint32_t j = threadIdx.x; j < qfloats; j += 256) dst[(size_t) s * qfloats + j] = j < dim ? q[j] : 0.0f;
 }
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem);
 
     for (uint32_t qi = tid; qi < (uint32_t) MF_NQ; qi += MF_THREADS) {
-        const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         ctrl[qi].count = 0;
         qnl[qi] = p.q_norm2[slot];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     }
     if (tid < 4) flags[tid] = 0;
     for (uint32_t qi = 0; qi < (uint32_t) MF_NQ; ++qi) {                       // pad columns repeat query 0
-        const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
         for (uint32_t i = tid; i < qpitch; i += MF_THREADS)
             qlds[(size_t) qi * qpitch + i] = i < stride4 ? qsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);

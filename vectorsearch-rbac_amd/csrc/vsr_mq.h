@@ -62,14 +62,14 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
 
     // ---- queries -> LDS (pad slots repeat query 0 so that every sub-batch is full) ----
     for (uint32_t qi = tid; qi < qmax; qi += MQ_THREADS) {
-        const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         ctrl[qi].count = 0;
         qnl[qi] = (METRIC == M_COSINE) ? p.q_norm2[slot] : 0.0f;
     }
     if (tid < 4) flags[tid] = 0;
     for (uint32_t qi = 0; qi < (uint32_t) NQ; ++qi) {
-        const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
         for (uint32_t i = tid; i < qpitch; i += MQ_THREADS)
             qlds[(size_t) qi * qpitch + i] = i < stride4 ? qsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);

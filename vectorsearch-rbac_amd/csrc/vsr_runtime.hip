@@ -138,6 +138,7 @@ struct vsr_ctx {
     uint32_t debug = 0;            // VSR_DEBUG bits (measurement only)
     double extra_ms[2] = {0, 0};   // sample scan, seed select (profiling only)
     unsigned long long* d_dbg = nullptr;
+    bool no_classes = false;       // VSR_NO_CLASSES=1: scan role partitions whole (A/B measurements)
     bool no_mq = false;            // VSR_NO_MQ=1: keep shared passes on K1 (A/B measurements)
 };
 
@@ -151,6 +152,9 @@ struct vsr_filter {
     bool        owns_bitmap = false;
     int64_t     allowed_rows = 0;
     int64_t     scanned_rows = 0;
+    // pre-filter of a role set = union of disjoint permission classes (documents with the same role signature);
+    // the planner scans class by class so that queries of different roles share the classes they have in common
+    std::vector<vsr_filter*> parts;
 };
 
 struct vsr_corpus {
@@ -179,6 +183,10 @@ struct vsr_corpus {
     uint64_t* d_doc_mask = nullptr;
     std::unordered_map<int32_t, std::vector<int32_t>> user_roles;
     std::map<std::pair<int, std::vector<int32_t>>, vsr_filter*> cache;
+    // permission classes: documents grouped by identical role signature (doc_mask row)
+    std::vector<uint32_t> doc_class;                 // per document
+    std::vector<std::vector<uint64_t>> class_sig;    // per class
+    std::vector<vsr_filter*> class_filters;          // per class, built on first use (RANGES, owned by the corpus)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -230,6 +238,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_MIN_ROWS_PER_BLOCK"))) ctx->min_rows_per_block = std::max(1, atoi(env));
     if ((env = getenv("VSR_MAX_QB"))) ctx->max_qb = std::max(1, atoi(env));
     if ((env = getenv("VSR_NO_MQ"))) ctx->no_mq = atoi(env) != 0;
+    if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
     if ((env = getenv("VSR_SEED_MIN_PASS"))) ctx->seed_min_pass_rows = atoll(env);
@@ -371,17 +380,14 @@ extern "C" int vsr_stats_reset(vsr_ctx* ctx)
 // ---------------------------------------------------------------------------------------------
 // corpus
 // ---------------------------------------------------------------------------------------------
+static void drop_cached_filters(vsr_corpus* c);
+
 extern "C" int vsr_corpus_free(vsr_corpus* c)
 {
     if (!c) return VSR_OK;
     (void) hipSetDevice(c->ctx->device);
     (void) hipStreamSynchronize(c->ctx->stream);
-    for (auto& kv : c->cache) {
-        vsr_filter* f = kv.second;
-        if (f->d_tiles) (void) hipFree(f->d_tiles);
-        if (f->d_bitmap && f->owns_bitmap) (void) hipFree(f->d_bitmap);
-        delete f;
-    }
+    drop_cached_filters(c);
     void* ptrs[] = {c->d_rows, c->d_norm2, c->d_norm2_max, c->d_block, c->d_doc, c->d_orig, c->d_row_docidx, c->d_doc_mask};
     for (void* p : ptrs)
         if (p) (void) hipFree(p);
@@ -488,6 +494,14 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
 // ---------------------------------------------------------------------------------------------
 static void drop_cached_filters(vsr_corpus* c)
 {
+    for (vsr_filter* f : c->class_filters)
+        if (f) {
+            if (f->d_tiles) (void) hipFree(f->d_tiles);
+            delete f;
+        }
+    c->class_filters.clear();
+    c->class_sig.clear();
+    c->doc_class.clear();
     for (auto& kv : c->cache) {
         vsr_filter* f = kv.second;
         if (f->d_tiles) (void) hipFree(f->d_tiles);
@@ -535,6 +549,22 @@ extern "C" int vsr_rbac_load(vsr_corpus* c, const int32_t* ur_user, const int32_
     HIPCHK(hipMalloc(&c->d_doc_mask, bytes));
     if (!c->doc_mask.empty())
         HIPCHK(hipMemcpy(c->d_doc_mask, c->doc_mask.data(), c->doc_mask.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    // permission classes = distinct role signatures of the documents
+    {
+        std::map<std::vector<uint64_t>, uint32_t> ids;
+        c->doc_class.assign(c->docs.size(), 0);
+        std::vector<uint64_t> sig(c->words);
+        for (size_t di = 0; di < c->docs.size(); ++di) {
+            std::copy(c->doc_mask.begin() + (long) (di * c->words), c->doc_mask.begin() + (long) ((di + 1) * c->words), sig.begin());
+            auto it = ids.find(sig);
+            if (it == ids.end()) {
+                it = ids.emplace(sig, (uint32_t) c->class_sig.size()).first;
+                c->class_sig.push_back(sig);
+            }
+            c->doc_class[di] = it->second;
+        }
+        c->class_filters.assign(c->class_sig.size(), nullptr);
+    }
     c->rbac = true;
     return VSR_OK;
 }
@@ -616,6 +646,39 @@ static bool doc_allowed(const vsr_corpus* c, size_t di, const std::vector<uint64
     return false;
 }
 
+constexpr size_t MAX_CLASSES = 4096;        // beyond this (e.g. random RBAC: a signature per document) filters stay whole
+constexpr size_t MAX_PARTS = 64;
+
+// the rows of one permission class as a RANGES filter (built once, owned by the corpus)
+static int class_filter(vsr_corpus* c, uint32_t cls, vsr_filter** out)
+{
+    if (c->class_filters[cls]) {
+        *out = c->class_filters[cls];
+        return VSR_OK;
+    }
+    std::unique_ptr<vsr_filter, void (*)(vsr_filter*)> f(new vsr_filter(), free_filter);
+    f->corpus = c;
+    f->mode = VSR_FILTER_RANGES;
+    f->cached = true;
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    int64_t rows = 0;
+    for (size_t di = 0; di < c->docs.size(); ++di) {
+        if (c->doc_class[di] != cls) continue;
+        const uint32_t s = c->doc_row_start[di], e = c->doc_row_start[di + 1];
+        rows += e - s;
+        if (!ranges.empty() && ranges.back().second == s) ranges.back().second = e;
+        else ranges.emplace_back(s, e);
+    }
+    std::vector<uint2> tiles;
+    ranges_to_tiles(ranges, c->shape.rw, tiles);
+    int rc = upload_tiles(f.get(), tiles);
+    if (rc) return rc;
+    f->allowed_rows = f->scanned_rows = rows;
+    c->class_filters[cls] = f.release();
+    *out = c->class_filters[cls];
+    return VSR_OK;
+}
+
 static int build_role_filter(vsr_corpus* c, const std::vector<int32_t>& roles, int mode, vsr_filter** out)
 {
     std::unique_ptr<vsr_filter, void (*)(vsr_filter*)> f(new vsr_filter(), free_filter);
@@ -638,6 +701,18 @@ static int build_role_filter(vsr_corpus* c, const std::vector<int32_t>& roles, i
         int rc = upload_tiles(f.get(), tiles);
         if (rc) return rc;
         f->scanned_rows = allowed;
+        // the same row set as a union of permission classes (used when many queries are searched together)
+        if (c->class_sig.size() <= MAX_CLASSES) {
+            for (uint32_t cls = 0; cls < (uint32_t) c->class_sig.size(); ++cls) {
+                bool hit = false;
+                for (uint32_t w = 0; w < c->words; ++w) hit |= (c->class_sig[cls][w] & m[w]) != 0;
+                if (!hit) continue;
+                vsr_filter* part = nullptr;
+                if ((rc = class_filter(c, cls, &part))) return rc;
+                if (part->n_tiles) f->parts.push_back(part);
+            }
+            if (f->parts.size() > MAX_PARTS || f->parts.size() < 2) f->parts.clear();
+        }
     } else {
         int rc = alloc_bitmap(f.get());
         if (rc) return rc;
@@ -805,46 +880,56 @@ namespace {
 constexpr uint32_t SEL_FANIN = 64;           // partial lists one K5 workgroup merges; more -> two levels
 
 struct Plan {
-    std::vector<uint32_t>    slot_query;     // slot -> caller query index
-    std::vector<ScanGroup>   groups;         // one K1 launch
+    // slot i = caller query i; passes address their queries through q_slots
+    std::vector<uint32_t>    q_slots;        // per pass: the slots of its queries, concatenated
+    std::vector<ScanGroup>   groups;         // one K1 / K1m / K2 launch
     uint32_t                 n_blocks = 0;
-    int                      qi = 1;         // kernel sub-batch width (1 or 4)
+    int                      qi = 1;         // K1 sub-batch width (1 or 4)
     bool                     mq = false;     // shared passes run on K1m (vsr_mq.h)
     bool                     k2 = false;     // shared passes run on K2 (MFMA screening) + K5r
-    uint32_t                 keep = 0;       // K2: candidates kept per query (kp)
+    uint32_t                 keep = 0;       // partial list length kp (K2: 2k screening survivors; else k)
     uint32_t                 rerank_base = 0;  // K2: first partial list holding the per-query screening survivors
     uint32_t                 n_scan_lists = 0;
     uint32_t                 qmax = 1;       // query slots per workgroup
+    std::vector<uint32_t>    list_ids;       // K5 indirection: per query the indices of its partial lists
     std::vector<SelectQuery> sel1;           // level-1 K5 items (only for queries with many partial lists)
     std::vector<SelectQuery> selq;           // final K5 item per query (slot order)
     std::vector<ScanGroup>   groups_s;       // sample pass (threshold seeding): same passes, fewer workgroups
     std::vector<SelectQuery> seedq;          // per query: merge the sample pass's lists into a seed threshold
     uint32_t                 n_blocks_s = 0;
     uint32_t                 n_partial_s = 0;
-    uint32_t                 n_partial = 0;  // K1 partial lists + level-1 K5 outputs
+    uint32_t                 n_partial = 0;  // scan partial lists + level-1 K5 outputs (+ K2 survivor lists)
     int64_t                  scan_rows = 0;
     int64_t                  scan_bytes = 0;
 };
 
-struct PassDesc {
-    const vsr_filter* f;
-    uint32_t q_begin, q_count;
-    int64_t rows;
-    uint32_t n_tiles;
+struct PassItem {
+    const vsr_filter* part;                  // atomic filter scanned (nullptr = whole corpus)
+    uint32_t          slot;
 };
 
 }  // namespace
 
+// Queries -> passes.  A filter that is a union of permission classes (vsr_filter::parts) is scanned class by class, so
+// that every query whose role sees a class shares that class's pass: the corpus is then read at most
+// ceil(queries of the class / qmax) times per class instead of once per role partition.
 static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow_screening,
                       const vsr_filter* const* filters, Plan& plan)
 {
     const vsr_ctx* ctx = c->ctx;
-    // queries sharing a filter share corpus passes: order slots by filter
-    std::vector<uint32_t> order((size_t) nq);
-    std::iota(order.begin(), order.end(), 0u);
     auto fof = [&](uint32_t q) { return filters ? filters[q] : nullptr; };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fof(a) < fof(b); });
-    plan.slot_query = order;
+
+    const bool decompose = nq >= 32 && !ctx->no_classes;
+    std::vector<PassItem> items;
+    items.reserve((size_t) nq * 2);
+    for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
+        const vsr_filter* f = fof(q);
+        if (decompose && f && !f->parts.empty())
+            for (const vsr_filter* part : f->parts) items.push_back({part, q});
+        else
+            items.push_back({f, q});
+    }
+    std::stable_sort(items.begin(), items.end(), [](const PassItem& a, const PassItem& b) { return a.part < b.part; });
 
     const bool mq_ok = mq_supported(c->dim) && mq_qmax(c->dim) >= 4 && !ctx->no_mq;
     // K2: matrix-core screening keeps 2k (>= 32) candidates per query, K5r re-ranks them exactly
@@ -853,27 +938,30 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
                        2 * keep + 256 <= 8192 && ctx->max_qb >= 16 && mfma_lds_bytes(c->stride4) <= 150 * 1024;
     int qmax = k2_ok ? 16 : std::min(ctx->max_qb, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
     qmax = qmax >= 4 ? qmax / 4 * 4 : 1;
-    std::vector<PassDesc> passes;
+
+    struct Pass { const vsr_filter* f; uint32_t q_off, q_count; int64_t rows; uint32_t n_tiles; };
+    std::vector<Pass> passes;
     uint32_t widest = 1;
-    for (uint32_t s = 0; s < (uint32_t) nq;) {
-        const vsr_filter* f = fof(order[s]);
-        uint32_t e = s;
-        while (e < (uint32_t) nq && fof(order[e]) == f) ++e;
-        for (uint32_t b = s; b < e;) {
-            const uint32_t cnt = std::min<uint32_t>(e - b, (uint32_t) qmax);
-            PassDesc pd;
+    for (size_t s = 0; s < items.size();) {
+        size_t e = s;
+        while (e < items.size() && items[e].part == items[s].part) ++e;
+        const vsr_filter* f = items[s].part;
+        for (size_t b = s; b < e;) {
+            const uint32_t cnt = (uint32_t) std::min<size_t>(e - b, (size_t) qmax);
+            Pass pd;
             pd.f = f;
-            pd.q_begin = b;
+            pd.q_off = (uint32_t) plan.q_slots.size();
             pd.q_count = cnt;
             pd.rows = f ? f->scanned_rows : c->n;
             pd.n_tiles = f ? f->n_tiles : (uint32_t) ((c->n + c->shape.rw - 1) / c->shape.rw);
+            for (uint32_t i = 0; i < cnt; ++i) plan.q_slots.push_back(items[b + i].slot);
             passes.push_back(pd);
             widest = std::max(widest, cnt);
             b += cnt;
         }
         s = e;
     }
-    // one launch: the 4-wide kernel as soon as any pass carries more than one query
+    // one launch: the shared-pass kernels as soon as any pass carries more than one query
     plan.qi = widest > 1 ? 4 : 1;
     plan.qmax = plan.qi == 1 ? 1 : (widest + 3) / 4 * 4;
     plan.k2 = plan.qi == 4 && k2_ok;
@@ -885,78 +973,82 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
     for (auto& p : passes) total_rows += std::max<int64_t>(p.rows, 1);
     const int64_t budget = ctx->block_budget > 0 ? ctx->block_budget : 4 * (int64_t) ctx->prop.multiProcessorCount;
 
-    plan.selq.resize((size_t) nq);
+    std::vector<std::vector<uint32_t>> lists_of((size_t) nq), lists_s_of((size_t) nq);
     for (auto& p : passes) {
+        if (p.n_tiles == 0 || p.rows == 0) continue;       // empty filter part: nothing to scan
         int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows - 1) / total_rows;
         const int64_t min_rows = p.q_count > 1 ? std::max<int64_t>(ctx->min_rows_per_block, 2048) : ctx->min_rows_per_block;
         nb = std::min<int64_t>(nb, std::max<int64_t>(1, p.rows / min_rows));   // shared passes need rows to prune on
         nb = std::min<int64_t>(nb, std::max<uint32_t>(1, p.n_tiles));
         nb = std::max<int64_t>(nb, 1);
-        const bool empty = p.n_tiles == 0 || p.rows == 0;
-        for (uint32_t qi = 0; qi < p.q_count; ++qi) {
-            SelectQuery sq;
-            sq.partial_begin = plan.n_partial + qi * (uint32_t) nb;
-            sq.n_lists = empty ? 0 : (uint32_t) nb;
-            sq.out_slot = order[p.q_begin + qi];
-            sq.dst_list = SEL_FINAL;
-            sq.allowed = (uint32_t) std::min<int64_t>(p.f ? p.f->allowed_rows : c->n, 0xFFFFFFFFll);
-            sq.pad = 0;
-            plan.selq[p.q_begin + qi] = sq;
-        }
-        if (empty) continue;
         ScanGroup g;
         g.tiles = p.f ? p.f->d_tiles : nullptr;
         g.bitmap = p.f ? p.f->d_bitmap : nullptr;
         g.n_tiles = p.n_tiles;
-        g.q_begin = p.q_begin;
+        g.q_begin = p.q_off;
         g.q_count = p.q_count;
         g.block_begin = plan.n_blocks;
         g.n_blocks = (uint32_t) nb;
         g.partial_begin = plan.n_partial;
         plan.groups.push_back(g);
-        {   // the same pass in the sample launch (aliases the partial / candidate buffers: it finishes first)
-            ScanGroup gs = g;
-            gs.n_blocks = (uint32_t) std::max<int64_t>(1, nb / SEED_BLOCK_DIV);
-            gs.block_begin = plan.n_blocks_s;
-            gs.partial_begin = plan.n_partial_s;
-            plan.groups_s.push_back(gs);
-            for (uint32_t qi = 0; qi < p.q_count; ++qi) {
-                SelectQuery sd;
-                sd.partial_begin = plan.n_partial_s + qi * gs.n_blocks;
-                sd.n_lists = gs.n_blocks;
-                sd.out_slot = p.q_begin + qi;          // thresholds are indexed by slot
-                sd.dst_list = SEL_SEED;
-                sd.allowed = 0;
-                sd.pad = 0;
-                plan.seedq.push_back(sd);
-            }
-            plan.n_blocks_s += gs.n_blocks;
-            plan.n_partial_s += gs.n_blocks * p.q_count;
+        ScanGroup gs = g;                                   // the same pass in the sample launch (buffers alias:
+        gs.n_blocks = (uint32_t) std::max<int64_t>(1, nb / SEED_BLOCK_DIV);   // it finishes before the main launch)
+        gs.block_begin = plan.n_blocks_s;
+        gs.partial_begin = plan.n_partial_s;
+        plan.groups_s.push_back(gs);
+        for (uint32_t qi = 0; qi < p.q_count; ++qi) {
+            const uint32_t slot = plan.q_slots[p.q_off + qi];
+            for (uint32_t b = 0; b < g.n_blocks; ++b) lists_of[slot].push_back(g.partial_begin + qi * g.n_blocks + b);
+            for (uint32_t b = 0; b < gs.n_blocks; ++b) lists_s_of[slot].push_back(gs.partial_begin + qi * gs.n_blocks + b);
         }
-        plan.n_blocks += (uint32_t) nb;
-        plan.n_partial += (uint32_t) nb * p.q_count;
+        plan.n_blocks += g.n_blocks;
+        plan.n_partial += g.n_blocks * p.q_count;
+        plan.n_blocks_s += gs.n_blocks;
+        plan.n_partial_s += gs.n_blocks * p.q_count;
         plan.scan_rows += p.rows;
         plan.scan_bytes += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12 +
                            (plan.k2 ? p.rows * 4 : 0);     // K2 also reads |row|^2
     }
     plan.n_scan_lists = plan.n_partial;
-    // queries with many partial lists get a first K5 level of SEL_FANIN-list merges
-    for (auto& sq : plan.selq) {
-        if (sq.n_lists <= SEL_FANIN) continue;
-        const uint32_t n1 = (sq.n_lists + SEL_FANIN - 1) / SEL_FANIN;
-        for (uint32_t j = 0; j < n1; ++j) {
-            SelectQuery s1;
-            s1.partial_begin = sq.partial_begin + j * SEL_FANIN;
-            s1.n_lists = std::min<uint32_t>(SEL_FANIN, sq.n_lists - j * SEL_FANIN);
-            s1.out_slot = 0;
-            s1.dst_list = plan.n_partial + j;
-            s1.allowed = 0;
-            s1.pad = 0;
-            plan.sel1.push_back(s1);
+
+    // K5 items.  Queries with many partial lists get a first level of SEL_FANIN-list merges.
+    plan.selq.resize((size_t) nq);
+    plan.seedq.resize((size_t) nq);
+    for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
+        const vsr_filter* f = fof(q);
+        const uint32_t allowed = (uint32_t) std::min<int64_t>(f ? f->allowed_rows : c->n, 0xFFFFFFFFll);
+        std::vector<uint32_t>& ls = lists_of[q];
+        if (ls.size() > SEL_FANIN) {
+            std::vector<uint32_t> level2;
+            for (size_t j = 0; j < ls.size(); j += SEL_FANIN) {
+                SelectQuery s1;
+                s1.ids_begin = (uint32_t) plan.list_ids.size();
+                s1.n_lists = (uint32_t) std::min<size_t>(SEL_FANIN, ls.size() - j);
+                s1.out_slot = 0;
+                s1.dst_list = plan.n_partial;
+                s1.allowed = 0;
+                s1.pad = 0;
+                plan.list_ids.insert(plan.list_ids.end(), ls.begin() + (long) j, ls.begin() + (long) (j + s1.n_lists));
+                plan.sel1.push_back(s1);
+                level2.push_back(plan.n_partial++);
+            }
+            ls.swap(level2);
         }
-        sq.partial_begin = plan.n_partial;
-        sq.n_lists = n1;
-        plan.n_partial += n1;
+        SelectQuery sq;
+        sq.ids_begin = (uint32_t) plan.list_ids.size();
+        sq.n_lists = (uint32_t) ls.size();
+        sq.out_slot = q;
+        sq.dst_list = SEL_FINAL;
+        sq.allowed = allowed;
+        sq.pad = 0;
+        plan.list_ids.insert(plan.list_ids.end(), ls.begin(), ls.end());
+        plan.selq[q] = sq;
+        SelectQuery sd = sq;                                // seed item: the sample pass's lists of the same query
+        sd.ids_begin = (uint32_t) plan.list_ids.size();
+        sd.n_lists = (uint32_t) lists_s_of[q].size();
+        sd.dst_list = SEL_SEED;
+        plan.list_ids.insert(plan.list_ids.end(), lists_s_of[q].begin(), lists_s_of[q].end());
+        plan.seedq[q] = sd;
     }
     if (plan.k2) {          // the final K5 of every query writes its kp screening survivors as list rerank_base + slot
         plan.rerank_base = plan.n_partial;
@@ -978,16 +1070,17 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
 
     const uint32_t kp = plan.keep;
     const size_t qfloats = (size_t) c->stride4 * 4;
-    // one staging block: [queries | q_norm2 | scan groups | level-1 select | final select | slot map]
+    // one staging block: [queries | q_norm2 | scan groups | sample groups | pass query slots | K5 items | list ids]
     const size_t off_q = 0;
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
     const size_t off_g = align_up(off_qn + (size_t) nq * sizeof(float), 256);
-    const size_t off_s1 = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
+    const size_t off_gs = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
+    const size_t off_qs = align_up(off_gs + plan.groups_s.size() * sizeof(ScanGroup), 256);
+    const size_t off_s1 = align_up(off_qs + plan.q_slots.size() * sizeof(uint32_t), 256);
     const size_t off_sq = align_up(off_s1 + plan.sel1.size() * sizeof(SelectQuery), 256);
-    const size_t off_gs = align_up(off_sq + plan.selq.size() * sizeof(SelectQuery), 256);   // sample-pass groups
-    const size_t off_sd = align_up(off_gs + plan.groups_s.size() * sizeof(ScanGroup), 256); // seed items
-    const size_t off_sl = align_up(off_sd + plan.seedq.size() * sizeof(SelectQuery), 256);
-    const size_t total = align_up(off_sl + (size_t) nq * sizeof(uint32_t), 256);
+    const size_t off_sd = align_up(off_sq + plan.selq.size() * sizeof(SelectQuery), 256);
+    const size_t off_li = align_up(off_sd + plan.seedq.size() * sizeof(SelectQuery), 256);
+    const size_t total = align_up(off_li + plan.list_ids.size() * sizeof(uint32_t), 256);
 
     int rc;
     if ((rc = ctx->h_desc.reserve(total))) return rc;
@@ -999,28 +1092,28 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     }
     char* hs = ctx->h_desc.as<char>();
     char* ds = ctx->d_desc.as<char>();
-    float* hq = reinterpret_cast<float*>(hs + off_q);
     if (h_queries) {
+        float* hq = reinterpret_cast<float*>(hs + off_q);
         for (int s = 0; s < nq; ++s) {
-            const float* src = h_queries + (size_t) plan.slot_query[(size_t) s] * dim;
             float* dst = hq + (size_t) s * qfloats;
-            memcpy(dst, src, (size_t) dim * sizeof(float));
+            memcpy(dst, h_queries + (size_t) s * dim, (size_t) dim * sizeof(float));
             for (size_t j = (size_t) dim; j < qfloats; ++j) dst[j] = 0.0f;
         }
     }
     memcpy(hs + off_g, plan.groups.data(), plan.groups.size() * sizeof(ScanGroup));
+    memcpy(hs + off_gs, plan.groups_s.data(), plan.groups_s.size() * sizeof(ScanGroup));
+    memcpy(hs + off_qs, plan.q_slots.data(), plan.q_slots.size() * sizeof(uint32_t));
     memcpy(hs + off_s1, plan.sel1.data(), plan.sel1.size() * sizeof(SelectQuery));
     memcpy(hs + off_sq, plan.selq.data(), plan.selq.size() * sizeof(SelectQuery));
-    memcpy(hs + off_gs, plan.groups_s.data(), plan.groups_s.size() * sizeof(ScanGroup));
     memcpy(hs + off_sd, plan.seedq.data(), plan.seedq.size() * sizeof(SelectQuery));
-    memcpy(hs + off_sl, plan.slot_query.data(), (size_t) nq * sizeof(uint32_t));
+    memcpy(hs + off_li, plan.list_ids.data(), plan.list_ids.size() * sizeof(uint32_t));
     if (h_queries) {
         HIPCHK(hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream));
     } else {
         HIPCHK(hipMemcpyAsync(ds + off_g, hs + off_g, total - off_g, hipMemcpyHostToDevice, ctx->stream));
-        // gather the caller's device queries into padded slot order
-        HIPCHK(launch_gather_queries(d_queries, reinterpret_cast<const uint32_t*>(ds + off_sl), (uint32_t) nq, (uint32_t) dim,
-                                     (uint32_t) qfloats, reinterpret_cast<float*>(ds + off_q), ctx->stream));
+        // pad the caller's device queries to the row stride (slot = query index)
+        HIPCHK(launch_gather_queries(d_queries, nullptr, (uint32_t) nq, (uint32_t) dim, (uint32_t) qfloats,
+                                     reinterpret_cast<float*>(ds + off_q), ctx->stream));
     }
     HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
     ctx->desc_pending = true;
@@ -1054,6 +1147,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     }
     sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
     sp.n_groups = (uint32_t) plan.groups.size();
+    sp.q_slots = reinterpret_cast<const uint32_t*>(ds + off_qs);
     if ((rc = ctx->d_flags.reserve((size_t) nq * sizeof(int32_t)))) return rc;
     HIPCHK(hipMemsetAsync(ctx->d_flags.p, 0, (size_t) nq * sizeof(int32_t), ctx->stream));
     if (metric == VSR_METRIC_COSINE || plan.k2)   // |q|^2 with the same kernel that made the row norms
@@ -1062,6 +1156,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
 
     SelectParams sel;
     sel.partial = ctx->d_partial.as<uint64_t>();
+    sel.list_ids = reinterpret_cast<const uint32_t*>(ds + off_li);
     sel.kp = kp;
     // short candidate streams (<= 16k keys per query) merge faster with small workgroups
     uint32_t max_lists = 1;
@@ -1086,8 +1181,8 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sel.tau_out = nullptr;
     sel.seeded = 0;
 
-    // ---- threshold seeding: a 1/32 sample pass of the same launch, then the m-th best sampled candidate of each
-    // query becomes the initial threshold of the main pass (all rows at or before it stay eligible; a query whose
+    // ---- threshold seeding: a 1/SEED_STRIDE sample pass of the same launch, then the m-th best sampled candidate of
+    // each query becomes the initial threshold of the main pass (all rows at or before it stay eligible; a query whose
     // seed turns out too tight is flagged by K5 / K5r and re-run unseeded) ----
     const bool seed = allow_screening && ctx->seeding && (plan.k2 || plan.mq) && plan.n_blocks > 0 &&
                       plan.scan_rows >= ctx->seed_min_rows &&

@@ -151,14 +151,14 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
     const uint32_t q_count = grp.q_count;
     const uint32_t n_sub = (q_count + QI - 1) / QI;                           // wave-uniform
     for (uint32_t qi = tid; qi < qmax; qi += SCAN_THREADS) {
-        const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         ctrl[qi].count = 0;
         qnl[qi] = (METRIC == M_COSINE) ? p.q_norm2[slot] : 0.0f;
     }
     if (tid < 4) flags[tid] = 0;
     for (uint32_t qi = 0; qi < n_sub * QI; ++qi) {                            // pad slots repeat query 0
-        const uint32_t slot = grp.q_begin + (qi < q_count ? qi : 0);
+        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
         for (uint32_t i = tid; i < stride4; i += SCAN_THREADS) qlds[(size_t) qi * stride4 + i] = qsrc[i];
     }
