@@ -50,6 +50,7 @@ struct ScanParams {
     const uint64_t*  tau_init;     // [n_slots] seeded thresholds (sample pass), nullptr = none
     uint32_t         sample_stride;  // 1 = every tile; S > 1 = sample pass over every S-th tile of each workgroup
     uint32_t         debug;        // measurement only: bit 0 = never append candidates (isolates the streaming/compute part)
+    uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
     unsigned long long* dbg;       // measurement only (VSR_DEBUG bit 1): [0] compactions, [1] appended keys, [2] tiles
 };
 
@@ -142,14 +143,15 @@ int  mq_qmax(int dim);
 hipError_t launch_mq(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
 // K2 (vsr_mfma.h): fp32-MFMA screening for shared passes (L2 / IP / cosine), followed by K5r
 hipError_t launch_mfma(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
-inline size_t mfma_lds_bytes(uint32_t stride4)
+inline size_t mfma_lds_bytes(uint32_t stride4, int nq = 16)
 {
     const uint32_t nstage = (stride4 + 15) / 16;
     return (size_t) 4 * 64 * 16 * 16                       // 4 wave staging images (swizzled, no padding)
-         + (size_t) 4 * 64 * 8                             // row index + |row|^2 per slot
-         + (size_t) 16 * nstage * 16 * 16                  // 16 queries, zero padded to whole stages
-         + (size_t) 16 * 20 + 32;
+         + (size_t) 4 * 128 * 8                            // row index + |row|^2 per slot, double-buffered
+         + (nstage > 4 ? (size_t) 16 * nstage * 16 * 16 : 0)   // queries in LDS only when they do not fit registers
+         + (size_t) nq * 20 + 32;
 }
+inline int mfma_qmax(uint32_t stride4) { return (stride4 + 15) / 16 <= 4 ? 32 : 16; }
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 256 | 1024

@@ -39,7 +39,8 @@ __device__ __forceinline__ float screen_value(float dot, float nx, float nq)
 
 // NSTR > 0: B fragments of NSTR stages live in registers (d <= 64 * NSTR); NSTR == 0: B read from LDS per use.
 // SAMPLE only gives the seeding pass (p.sample_stride > 1) its own kernel symbol in profiles.
-template <int METRIC, int NSTR, bool SAMPLE>
+// NG: 16-query groups served by one pass (1 or 2): the staged tile is multiplied against NG sets of B fragments.
+template <int METRIC, int NSTR, bool SAMPLE, int NG>
 __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -64,13 +65,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     unsigned char* after = smem + (size_t) MF_WAVES * 64 * MF_S * 16;
     int32_t*  rowidx = reinterpret_cast<int32_t*>(after) + wave * 64;
     float*    rownorm = reinterpret_cast<float*>(after + MF_WAVES * 64 * 4) + wave * 64;
-    float4*   qlds = reinterpret_cast<float4*>(after + MF_WAVES * 64 * 8);
-    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(qlds + (size_t) MF_NQ * qpitch);
-    float*    qnl = reinterpret_cast<float*>(ctrl + MF_NQ);
-    uint32_t* flags = reinterpret_cast<uint32_t*>(qnl + MF_NQ);
+    constexpr int NQ = MF_NQ * NG;
+    static_assert(NSTR > 0 || NG == 1, "LDS-resident queries: one group only");
+    float4*   qlds = reinterpret_cast<float4*>(after + MF_WAVES * 64 * 8);      // NSTR == 0 only
+    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(qlds + (NSTR == 0 ? (size_t) MF_NQ * qpitch : 0));
+    float*    qnl = reinterpret_cast<float*>(ctrl + NQ);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(qnl + NQ);
     uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem);
 
-    for (uint32_t qi = tid; qi < (uint32_t) MF_NQ; qi += MF_THREADS) {
+    for (uint32_t qi = tid; qi < (uint32_t) NQ; qi += MF_THREADS) {
         const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         ctrl[qi].count = 0;
@@ -79,11 +82,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
             atomicAdd(&p.dbg[p.tau_init[slot] == KEY_EMPTY ? 3 : 4], 1ull);
     }
     if (tid < 4) flags[tid] = 0;
-    for (uint32_t qi = 0; qi < (uint32_t) MF_NQ; ++qi) {                       // pad columns repeat query 0
-        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
-        const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
-        for (uint32_t i = tid; i < qpitch; i += MF_THREADS)
-            qlds[(size_t) qi * qpitch + i] = i < stride4 ? qsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (NSTR == 0) {
+        for (uint32_t qi = 0; qi < (uint32_t) MF_NQ; ++qi) {                   // pad columns repeat query 0
+            const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
+            const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
+            for (uint32_t i = tid; i < qpitch; i += MF_THREADS)
+                qlds[(size_t) qi * qpitch + i] = i < stride4 ? qsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __syncthreads();
 
@@ -92,16 +97,24 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     const int kq = lane >> 4;
     const int jq = li;
     constexpr int NB = NSTR > 0 ? NSTR : 1;
-    float4 bq[NB][4];
-    if constexpr (NSTR > 0) {
+    float4 bq[NG][NB][4];
+    float my_qn[NG];
 #pragma unroll
-        for (int s = 0; s < NSTR; ++s)
+    for (int g = 0; g < NG; ++g) {
+        const uint32_t qi = (uint32_t) (g * MF_NQ + jq);
+        my_qn[g] = qnl[qi];
+        if constexpr (NSTR > 0) {                                              // B fragments straight from global
+            const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
+            const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                bq[s][t] = (uint32_t) s < nstage ? qlds[(size_t) jq * qpitch + s * MF_S + 4 * t + kq]
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < NSTR; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t idx = (uint32_t) (s * MF_S + 4 * t + kq);
+                    bq[g][s][t] = idx < stride4 ? qsrc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
     }
-    const float my_qn = qnl[jq];
 
     const uint32_t rw = p.rw, tps = 64 / rw;
     const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
@@ -116,111 +129,210 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     const int lps_row = lane / MF_S, lps_chunk = lane % MF_S;
     constexpr int RPI = 64 / MF_S;
 
+    // ---- software pipeline across tiles: while the last stage of tile `it` is on the matrix cores, the row mapping of
+    // tile it+1 is already resolved and its first stage of row loads is in flight (the tile descriptor itself is
+    // fetched one step earlier still).  rowidx / rownorm are double-buffered per wave. ----
+    auto fetch_desc = [&](uint32_t it_) -> uint2 {               // (start, nrows) of this lane's list tile, or (0, 0)
+        const uint32_t sup = (it_ * MF_WAVES + wave) * ss;
+        if (it_ >= iters || sup >= n_super) return make_uint2(0u, 0u);
+        const uint32_t t = t0 + sup * tps + (uint32_t) lane / rw;
+        if (t >= t1) return make_uint2(0u, 0u);
+        if (t >= grp.n_tiles) {                                  // cannot happen; never read past the tile list
+            atomicOr(p.err, 4u);
+            return make_uint2(0u, 0u);
+        }
+        if (grp.tiles) return grp.tiles[t];
+        const uint32_t start = t * rw;
+        return make_uint2(start, p.n_rows - start < rw ? p.n_rows - start : rw);
+    };
+    auto resolve = [&](uint2 d) -> int32_t {                     // this lane's corpus row of the tile, or -1
+        const uint32_t r = (uint32_t) lane % rw;
+        if (r >= d.y) return -1;
+        const uint32_t row = d.x + r;
+        if (row >= p.n_rows) {                                   // cannot happen; never read past the corpus
+            atomicOr(p.err, 1u);
+            return -1;
+        }
+        if (grp.bitmap && !((grp.bitmap[row >> 6] >> (row & 63)) & 1ull)) return -1;
+        return (int32_t) row;
+    };
+    float4 x[MF_S];
+    auto issue = [&](uint32_t s, const int32_t* ridx) {           // global loads of stage s into x (no waits)
+        // branch-free: an invalid slot loads row 0 and is zeroed by a select, so that the 16 loads issue back to back
+        // (a branch around each load makes hipcc wait for every load separately)
+        const uint32_t chunk = s * MF_S + lps_chunk;
+        const bool okc = chunk < stride4;
+        const uint32_t cchunk = okc ? chunk : 0u;
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < MF_S; ++u) {
+            const int32_t r = ridx[u * RPI + lps_row];
+            const bool okr = r >= 0 && (uint32_t) r < p.n_rows;
+            bad |= r >= 0 && !okr;
+            const float4 v = p.rows[(size_t) (okr ? (uint32_t) r : 0u) * stride4 + cchunk];
+            x[u] = (okr && okc) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (bad) atomicOr(p.err, 1u);                                // cannot happen; never read past the corpus
+    };
+
+// Cross-tile software pipelining (next tile's row mapping + first loads issued under the current tile's last MFMA
+// stage) is written but OFF: the pipelined order hangs on hardware in a way not yet understood (round-1 notes in
+// DESIGN.md); the in-order variant below is the one that is tested and shipped.
+#ifndef VSR_K2_PIPELINE
+#define VSR_K2_PIPELINE 0
+#endif
+    int buf = 0;
+    int32_t myrow = -1;
+    float myrn = 0.0f;
+    bool have = false;
+#if VSR_K2_PIPELINE
+    myrow = resolve(fetch_desc(0));
+    myrn = myrow >= 0 ? p.norm2[myrow] : 0.0f;
+    have = __ballot(myrow >= 0) != 0;
+    if (have) {
+        rowidx[lane] = myrow;
+        issue(0, rowidx);
+    }
+#endif
     uint32_t round = 0;
     for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t sup = (it * MF_WAVES + wave) * ss;
-        int32_t myrow = -1;
-        if (sup < n_super) {
-            const uint32_t t = t0 + sup * tps + (uint32_t) lane / rw;
-            const uint32_t r = (uint32_t) lane % rw;
-            if (t < t1) {
-                uint32_t start, nrows;
-                if (grp.tiles) {
-                    const uint2 tl = grp.tiles[t];
-                    start = tl.x;
-                    nrows = tl.y;
-                } else {
-                    start = t * rw;
-                    nrows = p.n_rows - start < rw ? p.n_rows - start : rw;
-                }
-                if (r < nrows) {
-                    const uint32_t row = start + r;
-                    bool ok = true;
-                    if (grp.bitmap) ok = (grp.bitmap[row >> 6] >> (row & 63)) & 1ull;
-                    if (ok) myrow = (int32_t) row;
-                }
-            }
+        int32_t* ridx = rowidx + buf * 64;
+        float* rnrm = rownorm + buf * 64;
+#if VSR_K2_PIPELINE
+        int32_t* ridx_n = rowidx + (buf ^ 1) * 64;
+        const uint2 ndesc = fetch_desc(it + 1);                  // needed only at the last stage below
+#else
+        myrow = resolve(fetch_desc(it));
+        myrn = myrow >= 0 ? p.norm2[myrow] : 0.0f;
+        have = __ballot(myrow >= 0) != 0;
+        if (have) {
+            ridx[lane] = myrow;
+            issue(0, ridx);
         }
-        if (__ballot(myrow >= 0) != 0) {                                       // wave-uniform
+#endif
+#if VSR_K2_PIPELINE
+        int32_t nrow = -1;
+        float nrn = 0.0f;
+        bool nhave = false;
+#endif
+        auto prepare_next = [&]() {
+#if VSR_K2_PIPELINE
+            nrow = resolve(ndesc);
+            nhave = __ballot(nrow >= 0) != 0;
+            if (nhave) {
+                ridx_n[lane] = nrow;
+                nrn = nrow >= 0 ? p.norm2[nrow] : 0.0f;
+                issue(0, ridx_n);
+            }
+#endif
+        };
+        if (have) {                                                            // wave-uniform
             if (p.dbg && lane == 0) atomicAdd(&p.dbg[2], 1ull);
-            rowidx[lane] = myrow;
-            rownorm[lane] = myrow >= 0 ? p.norm2[myrow] : 0.0f;
+            rnrm[lane] = myrn;
 
-            f32x4 acc[4];
+            f32x4 acc[NG][4];
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub) acc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) acc[g][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-            float4 x[MF_S];
-            auto issue = [&](uint32_t s) {
-                const uint32_t chunk = s * MF_S + lps_chunk;
-#pragma unroll
-                for (int u = 0; u < MF_S; ++u) {
-                    const int32_t r = rowidx[u * RPI + lps_row];
-                    x[u] = (r >= 0 && chunk < stride4) ? p.rows[(size_t) r * stride4 + chunk]
-                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            };
-            issue(0);
             for (uint32_t s = 0; s < nstage; ++s) {
 #pragma unroll
                 for (int u = 0; u < MF_S; ++u) {
                     const int row = u * RPI + lps_row;
                     stage[row * MF_S + (lps_chunk ^ (row & 15))] = x[u];       // swizzled image
                 }
-                if (s + 1 < nstage) issue(s + 1);                              // in flight during the MFMAs
+                if (s + 1 < nstage) issue(s + 1, ridx);                        // in flight during the MFMAs
+                else prepare_next();                                           // next tile's first loads too
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    float4 b;
-                    if constexpr (NSTR > 0) {
-                        b = bq[0][t];
+                    float4 b[NG];
 #pragma unroll
-                        for (int ss = 1; ss < NSTR; ++ss)
-                            if (s == (uint32_t) ss) b = bq[ss][t];
-                    } else {
-                        b = qlds[(size_t) jq * qpitch + s * MF_S + 4 * t + kq];
-                    }
+                    for (int g = 0; g < NG; ++g) {
+                        if constexpr (NSTR > 0) {
+                            b[g] = bq[g][0][t];
 #pragma unroll
-                    for (int sub = 0; sub < 4; ++sub) {
-                        const int row = sub * 16 + li;
-                        const float4 a = stage[row * MF_S + ((4 * t + kq) ^ li)];
-                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[sub], 0, 0, 0);
-                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[sub], 0, 0, 0);
-                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[sub], 0, 0, 0);
-                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[sub], 0, 0, 0);
+                            for (int s2 = 1; s2 < NSTR; ++s2)
+                                if (s == (uint32_t) s2) b[g] = bq[g][s2][t];
+                        } else {
+                            b[g] = qlds[(size_t) jq * qpitch + s * MF_S + 4 * t + kq];
+                        }
                     }
+                    // A fragments of the four 16-row sub-tiles first, then the MFMAs component by component so that
+                    // consecutive instructions hit different accumulators (a dependent 16x16x4 chain has 40 cycles of
+                    // latency against a 32-cycle issue interval)
+                    float4 a[4];
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) a[sub] = stage[(sub * 16 + li) * MF_S + ((4 * t + kq) ^ li)];
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sub].x, b[g].x, acc[g][sub], 0, 0, 0);
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sub].y, b[g].y, acc[g][sub], 0, 0, 0);
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sub].z, b[g].z, acc[g][sub], 0, 0, 0);
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sub].w, b[g].w, acc[g][sub], 0, 0, 0);
                 }
             }
 
-            // results: acc[sub][r] = dot(row sub*16 + kq*4 + r, query jq).  Every lane screens its 16 (row, query jq)
-            // pairs, then reserves room for all of its survivors with ONE LDS atomic and stores them: no atomic
+            // results: acc[g][sub][r] = dot(row sub*16 + kq*4 + r, query g*16 + jq).  Every lane screens its 16 pairs per
+            // group, then reserves room for all of its survivors with ONE LDS atomic and stores them: no atomic
             // round trip per pair.
-            const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[jq].tau);
-            const bool qok = (uint32_t) jq < q_count && !(p.debug & 1u);
-            uint64_t keyv[16];
-            uint32_t pmask = 0;
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                const int4 ri = *reinterpret_cast<const int4*>(&rowidx[sub * 16 + kq * 4]);
-                const float4 rn = *reinterpret_cast<const float4*>(&rownorm[sub * 16 + kq * 4]);
-                const int32_t rows4[4] = {ri.x, ri.y, ri.z, ri.w};
-                const float nx4[4] = {rn.x, rn.y, rn.z, rn.w};
+            for (int g = 0; g < NG; ++g) {
+                const uint32_t qi = (uint32_t) (g * MF_NQ + jq);
+                const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[qi].tau);
+                const bool qok = qi < q_count && !(p.debug & 1u);
+                uint64_t keyv[16];
+                uint32_t pmask = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = screen_value<METRIC>(acc[sub][r], nx4[r], my_qn);
-                    keyv[sub * 4 + r] = make_key(v, (uint32_t) rows4[r]);
-                    if (qok && rows4[r] >= 0 && keyv[sub * 4 + r] < tau) pmask |= 1u << (sub * 4 + r);
+                for (int sub = 0; sub < 4; ++sub) {
+                    const int4 ri = *reinterpret_cast<const int4*>(&ridx[sub * 16 + kq * 4]);
+                    const float4 rn = *reinterpret_cast<const float4*>(&rnrm[sub * 16 + kq * 4]);
+                    const int32_t rows4[4] = {ri.x, ri.y, ri.z, ri.w};
+                    const float nx4[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = screen_value<METRIC>(acc[g][sub][r], nx4[r], my_qn[g]);
+                        keyv[sub * 4 + r] = make_key(v, (uint32_t) rows4[r]);
+                        if (qok && rows4[r] >= 0 && keyv[sub * 4 + r] < tau) pmask |= 1u << (sub * 4 + r);
+                    }
+                }
+                if (__ballot(pmask != 0) != 0) {                               // wave-uniform
+                    uint32_t base = 0;
+                    if (pmask) base = atomicAdd(&ctrl[qi].count, (uint32_t) __popc(pmask));
+                    if (pmask && base + (uint32_t) __popc(pmask) > cap) {      // cannot happen (append slack protocol)
+                        atomicOr(p.err, 2u);
+                        pmask = 0;
+                    }
+                    if (p.dbg && pmask) atomicAdd(&p.dbg[1], (unsigned long long) __popc(pmask));
+                    uint64_t* dst = cand + (size_t) qi * cand_qstride + base;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (pmask & (1u << i)) dst[__popc(pmask & ((1u << i) - 1u))] = keyv[i];
                 }
             }
-            if (__ballot(pmask != 0) != 0) {                                   // wave-uniform
-                uint32_t base = 0;
-                if (pmask) base = atomicAdd(&ctrl[jq].count, (uint32_t) __popc(pmask));
-                if (p.dbg && pmask) atomicAdd(&p.dbg[1], (unsigned long long) __popc(pmask));
-                uint64_t* dst = cand + (size_t) jq * cand_qstride + base;
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (pmask & (1u << i)) dst[__popc(pmask & ((1u << i) - 1u))] = keyv[i];
-            }
+        } else {
+            prepare_next();
         }
+#if VSR_K2_PIPELINE
+        myrow = nrow;
+        myrn = nrn;
+        have = nhave;
+        buf ^= 1;
+#endif
 
         if (it + 1 < iters) {
             bool need = false;
@@ -234,7 +346,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
             ++round;
             if (any) {
                 for (uint32_t q = 0; q < q_count; ++q) {
-                    const uint32_t n = ctrl[q].count;
+                    const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
                     if (n > trigger) {                                         // only the buffers that are filling up
                         if (p.dbg && tid == 0) atomicAdd(&p.dbg[0], 1ull);
                         uint64_t* cq = cand + (size_t) q * cand_qstride;
@@ -251,7 +363,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
 
     __syncthreads();
     for (uint32_t q = 0; q < q_count; ++q) {
-        const uint32_t n = ctrl[q].count;
+        const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
         const uint64_t* cq = cand + (size_t) q * cand_qstride;
         for (uint32_t i = tid; i < n; i += MF_THREADS) sortbuf[i] = cq[i];
         __syncthreads();
@@ -266,8 +378,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
 template <int METRIC>
 hipError_t launch_mfma_metric(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
 {
-    const size_t lds = mfma_lds_bytes(p.stride4);
     const uint32_t nstage = (p.stride4 + MF_S - 1) / MF_S;
+    const int ng = p.qmax > (uint32_t) MF_NQ ? 2 : 1;
+    const size_t lds = mfma_lds_bytes(p.stride4, ng * MF_NQ);
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -277,14 +390,17 @@ hipError_t launch_mfma_metric(const ScanParams& p, uint32_t n_blocks, hipStream_
         hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(MF_THREADS), lds, s, p);
         return hipGetLastError();
     };
-    if (p.sample_stride > 1) {
-        if (nstage <= 2) return launch(mfma_scan_kernel<METRIC, 2, true>);
-        if (nstage <= 4) return launch(mfma_scan_kernel<METRIC, 4, true>);
-        return launch(mfma_scan_kernel<METRIC, 0, true>);
+    const bool sample = p.sample_stride > 1;
+    if (nstage > 4) {
+        if (ng != 1) return hipErrorInvalidValue;
+        return sample ? launch(mfma_scan_kernel<METRIC, 0, true, 1>) : launch(mfma_scan_kernel<METRIC, 0, false, 1>);
     }
-    if (nstage <= 2) return launch(mfma_scan_kernel<METRIC, 2, false>);
-    if (nstage <= 4) return launch(mfma_scan_kernel<METRIC, 4, false>);
-    return launch(mfma_scan_kernel<METRIC, 0, false>);
+    if (nstage <= 2) {
+        if (ng == 2) return sample ? launch(mfma_scan_kernel<METRIC, 2, true, 2>) : launch(mfma_scan_kernel<METRIC, 2, false, 2>);
+        return sample ? launch(mfma_scan_kernel<METRIC, 2, true, 1>) : launch(mfma_scan_kernel<METRIC, 2, false, 1>);
+    }
+    if (ng == 2) return sample ? launch(mfma_scan_kernel<METRIC, 4, true, 2>) : launch(mfma_scan_kernel<METRIC, 4, false, 2>);
+    return sample ? launch(mfma_scan_kernel<METRIC, 4, true, 1>) : launch(mfma_scan_kernel<METRIC, 4, false, 1>);
 }
 
 }  // namespace vsr

@@ -134,7 +134,7 @@ struct vsr_ctx {
     // knobs
     int block_budget = 0;          // 0 = 4 * CUs
     int min_rows_per_block = 256;
-    int max_qb = SCAN_QMAX;
+    int max_qb = 32;
     uint32_t debug = 0;            // VSR_DEBUG bits (measurement only)
     double extra_ms[2] = {0, 0};   // sample scan, seed select (profiling only)
     unsigned long long* d_dbg = nullptr;
@@ -936,7 +936,7 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
     const uint32_t keep = (uint32_t) std::max(2 * k, 32);
     const bool k2_ok = allow_screening && ctx->screening && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
                        2 * keep + 256 <= 8192 && ctx->max_qb >= 16 && mfma_lds_bytes(c->stride4) <= 150 * 1024;
-    int qmax = k2_ok ? 16 : std::min(ctx->max_qb, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
+    int qmax = k2_ok ? std::min(ctx->max_qb, mfma_qmax(c->stride4)) : std::min(ctx->max_qb, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
     qmax = qmax >= 4 ? qmax / 4 * 4 : 1;
 
     struct Pass { const vsr_filter* f; uint32_t q_off, q_count; int64_t rows; uint32_t n_tiles; };
@@ -967,7 +967,7 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
     plan.k2 = plan.qi == 4 && k2_ok;
     plan.mq = plan.qi == 4 && mq_ok && !plan.k2;
     plan.keep = plan.k2 ? keep : (uint32_t) k;
-    if (plan.k2) plan.qmax = 16;
+    if (plan.k2) plan.qmax = plan.qmax > 16 ? 32 : 16;
 
     int64_t total_rows = 0;
     for (auto& p : passes) total_rows += std::max<int64_t>(p.rows, 1);
@@ -1133,6 +1133,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sp.rw = (uint32_t) c->shape.rw;
     sp.cand = nullptr;
     sp.debug = ctx->debug;
+    sp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;    // bounds-guard word (checked by vsr_screening_check)
     sp.dbg = nullptr;
     if (ctx->debug & 2u) {
         if (!ctx->d_dbg) {
@@ -1399,8 +1400,11 @@ extern "C" int vsr_screening_check(vsr_ctx* ctx, int64_t* flagged_total, int32_t
     if (!ctx) return fail(VSR_ERR_INVALID, "vsr_screening_check: ctx is NULL");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    int32_t total = 0;
-    HIPCHK(hipMemcpy(&total, ctx->d_flag_total, sizeof(int32_t), hipMemcpyDeviceToHost));
+    int32_t words[8] = {0};
+    HIPCHK(hipMemcpy(words, ctx->d_flag_total, sizeof words, hipMemcpyDeviceToHost));
+    const int32_t total = words[0];
+    if (words[4] != 0)
+        return fail(VSR_ERR_HIP, "internal bounds guard tripped in a scan kernel (bits %d): results are not valid", words[4]);
     if (flagged_total) *flagged_total = total;
     if (flags_last_call && nq > 0) {
         if (!ctx->d_flags.p || ctx->d_flags.cap < (size_t) nq * sizeof(int32_t))
