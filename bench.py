@@ -171,7 +171,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "vsr::mfma_scan_kernel<L2, 2, false> (K2 main pass)" if cls else
+        "kernel": "vsr::mfma_scan_kernel<L2, NSTR=2, SAMPLE=false, NG=1> (K2 main pass)" if cls else
                   "vsr::scan_kernel<L2, LPR=32, C=1, R=8, QI=1>",
         "launch_ms": round(ms_avg, 4), "bytes_per_launch": int(bytes_per_launch),
         "launches": int(launches),
@@ -185,7 +185,7 @@ def main():
             tr = json.load(f)
         if tr.get("workload") == workload_tag:
             for name, v in tr["kernels"].items():
-                main = ("mfma_scan_kernel" in name and "false>" in name) if cls else ("vsr::scan_kernel" in name)
+                main = ("mfma_scan_kernel" in name and "false" in name) if cls else ("vsr::scan_kernel" in name)
                 if main:
                     roofline["traffic"] = int(v["hbm_bytes_per_launch"])
                     roofline["traffic_source"] = os.path.relpath(args.traffic, ROOT) + ": " + tr["method"]

@@ -353,6 +353,61 @@ def test_unsorted_identities_are_reordered(ctx, oracle):
 
 
 # ---------------------------------------------------------------------------------------------
+# BASELINE config 3 shape: 768-d cosine, L2-normalised rows, tree RBAC (class passes), k = 100
+# (scaled to 200k rows so that the oracle finishes in seconds; the kernels are the full-size ones)
+# ---------------------------------------------------------------------------------------------
+def test_config3_768d_cosine_tree_rbac(ctx, oracle):
+    from vsrbac.datasets import gaussian_corpus, tree_rbac
+    from vsrbac.harness import Deployment
+    n, dim, k = 200_000, 768, 100
+    x, blk, doc = gaussian_corpus(n, dim, seed=3, normalize=True, blocks_per_doc=10)
+    ndocs = int(doc.max())
+    rbac = tree_rbac(num_users=200, num_roles=40, num_docs=ndocs, seed=3)
+    corpus = ctx.load_corpus(x, blk, doc)
+    corpus.load_rbac(rbac.user_roles, rbac.permissions)
+    rng = np.random.default_rng(31)
+    users = rng.integers(1, 201, 48)
+    q = x[rng.integers(0, n, 48)] + 0.05 * rng.normal(size=(48, dim)).astype(np.float32)
+    filters = [corpus.filter_for_user(int(u)) for u in users]
+    res = corpus.search(q, k, "cosine", filters)                    # 48 queries: class passes on the matrix cores
+    for i in range(0, 48, 6):
+        mask = oracle.user_row_mask(int(users[i]), rbac.user_roles, rbac.permissions, doc)
+        ref = _ref_all("cosine", x, q[i])
+        m = res.counts[i]
+        assert m == k
+        assert_valid_topk(res.rows[i, :m], res.dist[i, :m], ref, k, TOL, candidates=np.flatnonzero(mask))
+        oidx, odist = oracle.filtered_topk("cosine", x, q[i], k, doc, blk, mask)
+        np.testing.assert_allclose(res.dist[i, :m], odist, rtol=TOL, atol=TOL)
+        assert len(set(res.rows[i, :m].tolist()) & set(oidx.tolist())) >= k - 1     # ids equal up to a boundary near-tie
+    for i in range(48):                                             # properties on every query
+        assert res.counts[i] == k and (np.diff(res.dist[i]) >= -1e-6).all()
+        assert np.isin(res.doc_ids[i], rbac.visible_docs(int(users[i]))).all()
+    corpus.free()
+
+
+def test_config5_batched_queries_arbitrary_predicate(ctx, oracle):
+    """1000 batched queries, 768-d inner product, an arbitrary per-query-group byte mask (ACORN-style predicate:
+    acorn_benchmark/src/benchmark_utils.cpp:342-396) AND-ed with nothing else: exact filtered top-k per query."""
+    n, dim, k, nq = 60_000, 768, 100, 1000
+    rng = np.random.default_rng(32)
+    x = rng.normal(size=(n, dim)).astype(np.float32)
+    q = rng.normal(size=(nq, dim)).astype(np.float32)
+    corpus = ctx.load_corpus(x)
+    masks = [(rng.random(n) < p).astype(np.uint8) for p in (0.5, 0.1, 0.02, 0.9)]
+    fs = [corpus.filter_from_bytemask(m) for m in masks]
+    filters = [fs[i % 4] for i in range(nq)]
+    res = corpus.search(q, k, "ip", filters)
+    for i in range(0, nq, 97):
+        ref = _ref_all("ip", x, q[i])
+        cand = np.flatnonzero(masks[i % 4])
+        m = res.counts[i]
+        assert m == min(k, cand.size)
+        assert_valid_topk(res.rows[i, :m], res.dist[i, :m], ref, k, TOL, candidates=cand)
+    assert (res.counts == k).all()
+    corpus.free()
+
+
+# ---------------------------------------------------------------------------------------------
 # BASELINE config 2 at full size: SIFT1M-like, k = 100, role-partition prefilter (one GPU)
 # ---------------------------------------------------------------------------------------------
 def test_config2_sift1m_role_prefilter(ctx, oracle):

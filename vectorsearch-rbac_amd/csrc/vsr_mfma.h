@@ -223,6 +223,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                 ridx_n[lane] = nrow;
                 nrn = nrow >= 0 ? p.norm2[nrow] : 0.0f;
                 issue(0, ridx_n);
+#if VSR_K2_PIPELINE == 2
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // diagnostic: no load in flight past this point
+#endif
             }
 #endif
         };

@@ -134,7 +134,8 @@ struct vsr_ctx {
     // knobs
     int block_budget = 0;          // 0 = 4 * CUs
     int min_rows_per_block = 256;
-    int max_qb = 32;
+    int max_qb = 16;               // queries per shared pass; 32 (two MFMA query groups) is built and tested but does
+                                   // not raise throughput on MI355X (measured), it only shrinks the algorithmic bytes
     uint32_t debug = 0;            // VSR_DEBUG bits (measurement only)
     double extra_ms[2] = {0, 0};   // sample scan, seed select (profiling only)
     unsigned long long* d_dbg = nullptr;
