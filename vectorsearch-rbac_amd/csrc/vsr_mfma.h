@@ -63,11 +63,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
 
     float4*   stage = reinterpret_cast<float4*>(smem) + (size_t) wave * 64 * MF_S;
     unsigned char* after = smem + (size_t) MF_WAVES * 64 * MF_S * 16;
-    int32_t*  rowidx = reinterpret_cast<int32_t*>(after) + wave * 64;
-    float*    rownorm = reinterpret_cast<float*>(after + MF_WAVES * 64 * 4) + wave * 64;
+    int32_t*  rowidx = reinterpret_cast<int32_t*>(after) + wave * 128;             // [wave][2][64]
+    float*    rownorm = reinterpret_cast<float*>(after + MF_WAVES * 128 * 4) + wave * 128;
     constexpr int NQ = MF_NQ * NG;
     static_assert(NSTR > 0 || NG == 1, "LDS-resident queries: one group only");
-    float4*   qlds = reinterpret_cast<float4*>(after + MF_WAVES * 64 * 8);      // NSTR == 0 only
+    float4*   qlds = reinterpret_cast<float4*>(after + MF_WAVES * 128 * 8);      // NSTR == 0 only
     TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(qlds + (NSTR == 0 ? (size_t) MF_NQ * qpitch : 0));
     float*    qnl = reinterpret_cast<float*>(ctrl + NQ);
     uint32_t* flags = reinterpret_cast<uint32_t*>(qnl + NQ);
