@@ -297,6 +297,33 @@ def test_cosine_nan_rows_sort_last(ctx, oracle):
     corpus.free()
 
 
+def test_nonfinite_and_overflowing_rows_under_shared_passes(ctx, oracle):
+    """pgvector rejects NaN / Inf elements on input (vector.c:101-113) but accepts finite rows whose distance overflows
+    (vector_type.out:387-391).  The loader accepts both; such a corpus must stay off the matrix-core screening (its
+    error bound is not finite) and batched queries must still follow the oracle: Inf distances after the finite ones,
+    NaN last."""
+    rng = np.random.default_rng(21)
+    n, dim = 2000, 100                                   # dim 100: ragged last stage of the K2 staging image
+    x = sift_like(rng, n, dim)
+    x[17, 3] = np.inf
+    x[1200, :] = 3e38                                    # finite row, |row|^2 overflows
+    x[1900, 99] = -np.inf
+    blk, doc = _ids(n, 50)
+    corpus = ctx.load_corpus(x, blk, doc)
+    q = x[rng.integers(20, 1000, 5)].copy()
+    before, _ = ctx.screening_check(0)
+    for k in (10, n):                                    # k = n: the Inf / NaN tail is part of the answer
+        res = corpus.search(q, k, "l2")
+        for i in range(5):
+            idx, dist = oracle.filtered_topk("l2", x, q[i], k, doc, blk)
+            m = res.counts[i]
+            assert m == idx.size
+            np.testing.assert_array_equal(res.rows[i, :m], idx)
+            np.testing.assert_array_equal(res.dist[i, :m], dist.astype(np.float32))
+    assert ctx.screening_check(0)[0] == before           # never screened, so never flagged
+    corpus.free()
+
+
 # ---------------------------------------------------------------------------------------------
 # k range, empty / ragged inputs
 # ---------------------------------------------------------------------------------------------

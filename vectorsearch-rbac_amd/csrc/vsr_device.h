@@ -151,6 +151,20 @@ inline size_t mfma_lds_bytes(uint32_t stride4, int nq = 16)
          + (nstage > 4 ? (size_t) 16 * nstage * 16 * 16 : 0)   // queries in LDS only when they do not fit registers
          + (size_t) nq * 20 + 32;
 }
+// K2 workgroups vote on compaction every K2_VOTE_EVERY tiles per wave (a workgroup barrier per tile costs more than
+// the rare compaction it guards once thresholds are seeded); between two votes a query can gain K2_SLACK keys.
+// Candidate buffers are cap keys long but CAND_SKEW keys apart more: a power-of-two pitch would put the (short) filled
+// head of every buffer on the same few memory channels.
+constexpr uint32_t CAND_SKEW = 32;
+__host__ __device__ inline size_t cand_pitch(uint32_t cap) { return (size_t) cap + CAND_SKEW; }
+constexpr uint32_t K2_VOTE_EVERY = 4;
+constexpr uint32_t K2_SLACK = 4 * 64 * K2_VOTE_EVERY;
+inline uint32_t mfma_cap_for_k(uint32_t kp)
+{
+    uint32_t cap = 512;
+    while (cap < 2 * kp + K2_SLACK) cap <<= 1;
+    return cap;                    // sorted in the staging LDS: must stay <= 8192 keys (planner gate)
+}
 inline int mfma_qmax(uint32_t stride4) { return (stride4 + 15) / 16 <= 4 ? 32 : 16; }
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);

@@ -606,7 +606,10 @@ hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t 
 __global__ __launch_bounds__(256) void norm_max_kernel(const float* norm2, uint32_t n, uint32_t* out_bits)
 {
     float m = 0.0f;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = fmaxf(m, norm2[i]);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float v = norm2[i];
+        m = fmaxf(m, v < INFINITY ? v : INFINITY);                           // NaN counts as +Inf (fmaxf would drop it)
+    }
     for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order as uints
 }

@@ -27,7 +27,8 @@ constexpr int MF_THREADS = 256;
 constexpr int MF_WAVES = 4;
 constexpr int MF_S = 16;                  // float4 chunks per stage
 constexpr int MF_NQ = 16;                 // query columns of one MFMA tile
-constexpr int MF_SLACK = MF_WAVES * 64;   // keys per query a workgroup can append between two votes
+constexpr uint32_t MF_SLACK = K2_SLACK;    // keys per query a workgroup can append between two votes
+static_assert(K2_SLACK == MF_WAVES * 64 * K2_VOTE_EVERY, "slack covers one vote interval of every wave");
 
 template <int METRIC>
 __device__ __forceinline__ float screen_value(float dot, float nx, float nq)
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     const uint32_t ss = p.sample_stride;                                       // sample pass: every ss-th super-tile
     const uint32_t iters = ((n_super + ss - 1) / ss + MF_WAVES - 1) / MF_WAVES;
     const uint32_t trigger = cap - MF_SLACK;
-    uint64_t* cand = p.cand + (size_t) (grp.partial_begin + local_block) * cap;
-    const size_t cand_qstride = (size_t) grp.n_blocks * cap;
+    uint64_t* cand = p.cand + (size_t) (grp.partial_begin + local_block) * cand_pitch(cap);
+    const size_t cand_qstride = (size_t) grp.n_blocks * cand_pitch(cap);
 
     const int lps_row = lane / MF_S, lps_chunk = lane % MF_S;
     constexpr int RPI = 64 / MF_S;
@@ -158,21 +159,25 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     };
     float4 x[MF_S];
     auto issue = [&](uint32_t s, const int32_t* ridx) {           // global loads of stage s into x (no waits)
-        // branch-free: an invalid slot loads row 0 and is zeroed by a select, so that the 16 loads issue back to back
-        // (a branch around each load makes hipcc wait for every load separately)
+        // Nothing may consume the loaded registers here: any VALU touch (a select that zeroes an invalid slot) makes
+        // hipcc wait for the loads BEFORE the MFMAs of the previous stage, which serialises streaming and matrix work.
+        // An invalid slot (masked row, ragged tile) loads row 0 instead and its products are discarded by the
+        // `rows4[r] >= 0` test of the epilogue; the padding chunks of a ragged last stage load chunk 0 and meet the
+        // zero padding of the B fragments (finite x 0: the runtime keeps corpora with NaN / Inf elements off K2).
         const uint32_t chunk = s * MF_S + lps_chunk;
-        const bool okc = chunk < stride4;
-        const uint32_t cchunk = okc ? chunk : 0u;
-        bool bad = false;
+        const uint32_t cchunk = chunk < stride4 ? chunk : 0u;
+        int32_t worst = -1;
+        const uint32_t last = p.n_rows - 1u;
 #pragma unroll
         for (int u = 0; u < MF_S; ++u) {
             const int32_t r = ridx[u * RPI + lps_row];
-            const bool okr = r >= 0 && (uint32_t) r < p.n_rows;
-            bad |= r >= 0 && !okr;
-            const float4 v = p.rows[(size_t) (okr ? (uint32_t) r : 0u) * stride4 + cchunk];
-            x[u] = (okr && okc) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            worst = r > worst ? r : worst;
+            const uint32_t rc = (uint32_t) (r < 0 ? 0 : r);
+            // (loaded as a native vector: a float4 struct copy from global memory keeps x[] out of registers)
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.rows + (size_t) (rc < last ? rc : last) * stride4 + cchunk);
+            x[u] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        if (bad) atomicOr(p.err, 1u);                                // cannot happen; never read past the corpus
+        if (worst >= 0 && (uint32_t) worst >= p.n_rows) atomicOr(p.err, 1u);   // cannot happen; never read past the corpus
     };
 
 // Cross-tile software pipelining (next tile's row mapping + first loads issued under the current tile's last MFMA
@@ -194,6 +199,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
         issue(0, rowidx);
     }
 #endif
+#if !VSR_K2_PIPELINE
+    uint2 desc0 = fetch_desc(0);
+#endif
     uint32_t round = 0;
     for (uint32_t it = 0; it < iters; ++it) {
         int32_t* ridx = rowidx + buf * 64;
@@ -202,13 +210,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
         int32_t* ridx_n = rowidx + (buf ^ 1) * 64;
         const uint2 ndesc = fetch_desc(it + 1);                  // needed only at the last stage below
 #else
-        myrow = resolve(fetch_desc(it));
+        myrow = resolve(desc0);
         myrn = myrow >= 0 ? p.norm2[myrow] : 0.0f;
         have = __ballot(myrow >= 0) != 0;
         if (have) {
             ridx[lane] = myrow;
             issue(0, ridx);
         }
+        desc0 = fetch_desc(it + 1);                              // next tile's descriptor rides under this tile's work
 #endif
 #if VSR_K2_PIPELINE
         int32_t nrow = -1;
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                     uint64_t* dst = cand + (size_t) qi * cand_qstride + base;
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        if (pmask & (1u << i)) dst[__popc(pmask & ((1u << i) - 1u))] = keyv[i];
+                        if ((pmask & (1u << i)) && !(p.debug & 32u)) dst[__popc(pmask & ((1u << i) - 1u))] = keyv[i];
                 }
             }
         } else {
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
         buf ^= 1;
 #endif
 
-        if (it + 1 < iters) {
+        if (it + 1 < iters && (it + 1) % K2_VOTE_EVERY == 0) {
             bool need = false;
             for (uint32_t q = 0; q < q_count; ++q)
                 need |= *reinterpret_cast<volatile uint32_t*>(&ctrl[q].count) > trigger;
@@ -365,6 +374,28 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     }
 
     __syncthreads();
+    if (cap <= (uint32_t) (64 * MF_S * 16 / 8)) {
+        // publish, one wave per query: each wave sorts inside its own staging image, no workgroup barriers
+        uint64_t* wbuf = reinterpret_cast<uint64_t*>(stage);
+        for (uint32_t q = (uint32_t) wave; q < q_count; q += MF_WAVES) {
+            const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
+            const uint64_t* cq = cand + (size_t) q * cand_qstride;
+            uint64_t* dst = p.partial + (size_t) (grp.partial_begin + q * grp.n_blocks + local_block) * p.kp;
+            if (n <= keep) {                                                   // nothing to drop: order is K5's job
+                for (uint32_t i = (uint32_t) lane; i < p.kp; i += 64) dst[i] = i < n ? cq[i] : KEY_EMPTY;
+                continue;
+            }
+            const uint32_t np2 = next_pow2(n);
+            for (uint32_t i = (uint32_t) lane; i < np2; i += 64) wbuf[i] = i < n ? cq[i] : KEY_EMPTY;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            bitonic_sort_wave(wbuf, np2, lane);
+            for (uint32_t i = (uint32_t) lane; i < p.kp; i += 64) dst[i] = i < keep ? wbuf[i] : KEY_EMPTY;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     for (uint32_t q = 0; q < q_count; ++q) {
         const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
         const uint64_t* cq = cand + (size_t) q * cand_qstride;

@@ -85,8 +85,8 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
     const uint32_t ss = p.sample_stride;                                       // sample pass: every ss-th super-tile
     const uint32_t iters = ((n_super + ss - 1) / ss + MQ_WAVES - 1) / MQ_WAVES;
     const uint32_t trigger = cap - MQ_SLACK;
-    uint64_t* cand = p.cand + (size_t) (grp.partial_begin + local_block) * cap;   // + qs * n_blocks * cap
-    const size_t cand_qstride = (size_t) grp.n_blocks * cap;
+    uint64_t* cand = p.cand + (size_t) (grp.partial_begin + local_block) * cand_pitch(cap);   // + qs * n_blocks * cap
+    const size_t cand_qstride = (size_t) grp.n_blocks * cand_pitch(cap);
 
     const int lps_row = lane / MQ_S;          // which of the 64/S rows of a load instruction
     const int lps_chunk = lane % MQ_S;        // which chunk of the stage

@@ -116,7 +116,7 @@ struct vsr_ctx {
     DevBuf d_tau;        // seeded thresholds (sample pass)
     bool   seeding = true;        // seed thresholds of big shared passes from a 1/32 sample pass
     int64_t seed_min_rows = 2000000;
-    int64_t seed_min_pass_rows = 16384;  // average rows per pass below which the warm-up it removes is too small to pay
+    int64_t seed_min_pass_rows = 2048;   // average rows per pass below which the warm-up it removes is too small to pay
     int32_t* d_flag_total = nullptr;   // running count of flagged queries (device)
     bool   screening = true;      // allow K2 (MFMA screening + exact re-rank) for shared passes
     int64_t flagged_seen = 0;
@@ -167,7 +167,8 @@ struct vsr_corpus {
     KernelShape shape{};
     float4*     d_rows = nullptr;
     float*      d_norm2 = nullptr;
-    float*      d_norm2_max = nullptr;   // max |row|^2 (error bound of K2 screening)
+    float*      d_norm2_max = nullptr;   // max |row|^2 (error bound of K2 screening); +Inf if any |row|^2 is not finite
+    bool        k2_safe = true;          // false: some |row|^2 is Inf / NaN (non-finite or huge elements) -> exact kernels only
     int64_t*    d_block = nullptr;
     int32_t*    d_doc = nullptr;
     int64_t*    d_orig = nullptr;
@@ -485,6 +486,11 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
         HIPCHK(launch_row_norms(c->d_rows, (uint32_t) n, c->stride4, c->d_norm2, ctx->stream));
         HIPCHK(launch_norm_max(c->d_norm2, (uint32_t) n, c->d_norm2_max, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        // K2 multiplies the zero padding of its query fragments with row data and needs a finite error bound: a corpus
+        // holding NaN / Inf (pgvector rejects those on input, vector.c:101-113) or overflowing norms stays on K1 / K1m
+        float nmax = 0.0f;
+        HIPCHK(hipMemcpy(&nmax, c->d_norm2_max, sizeof(float), hipMemcpyDeviceToHost));
+        c->k2_safe = std::isfinite(nmax);
     }
     *out = c.release();
     return VSR_OK;
@@ -935,8 +941,8 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
     const bool mq_ok = mq_supported(c->dim) && mq_qmax(c->dim) >= 4 && !ctx->no_mq;
     // K2: matrix-core screening keeps 2k (>= 32) candidates per query, K5r re-ranks them exactly
     const uint32_t keep = (uint32_t) std::max(2 * k, 32);
-    const bool k2_ok = allow_screening && ctx->screening && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
-                       2 * keep + 256 <= 8192 && ctx->max_qb >= 16 && mfma_lds_bytes(c->stride4) <= 150 * 1024;
+    const bool k2_ok = allow_screening && ctx->screening && c->k2_safe && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
+                       mfma_cap_for_k(keep) <= 8192 && ctx->max_qb >= 16 && mfma_lds_bytes(c->stride4) <= 150 * 1024;
     int qmax = k2_ok ? std::min(ctx->max_qb, mfma_qmax(c->stride4)) : std::min(ctx->max_qb, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
     qmax = qmax >= 4 ? qmax / 4 * 4 : 1;
 
@@ -1129,7 +1135,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sp.partial = ctx->d_partial.as<uint64_t>();
     sp.kp = kp;
     sp.k = kp;
-    sp.cap = scan_cap_for_k((int) kp, c->dim);
+    sp.cap = plan.k2 ? mfma_cap_for_k(kp) : scan_cap_for_k((int) kp, c->dim);
     sp.qmax = plan.qmax;
     sp.rw = (uint32_t) c->shape.rw;
     sp.cand = nullptr;
@@ -1144,7 +1150,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
         sp.dbg = ctx->d_dbg;
     }
     if (plan.mq || plan.k2) {
-        if ((rc = ctx->d_cand.reserve(std::max<size_t>(8, (size_t) plan.n_scan_lists * sp.cap * sizeof(uint64_t))))) return rc;
+        if ((rc = ctx->d_cand.reserve(std::max<size_t>(8, (size_t) plan.n_scan_lists * cand_pitch(sp.cap) * sizeof(uint64_t))))) return rc;
         sp.cand = ctx->d_cand.as<uint64_t>();
     }
     sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);

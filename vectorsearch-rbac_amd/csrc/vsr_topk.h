@@ -75,6 +75,28 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t n, int
     }
 }
 
+// The same sort by ONE wave over keys only it touches: no workgroup barrier (a wave's LDS operations execute in
+// order; the wavefront fence keeps the compiler from moving them across the stage boundary).
+__device__ __forceinline__ void bitonic_sort_wave(uint64_t* keys, uint32_t n, int lane)
+{
+    for (uint32_t size = 2; size <= n; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = (uint32_t) lane; t < (n >> 1); t += 64) {
+                const uint32_t i = 2 * t - (t & (stride - 1));
+                const uint32_t j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = keys[i], b = keys[j];
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[j] = a;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t next_pow2(uint32_t v)
 {
     return v <= 2 ? 2u : 1u << (32 - __clz(v - 1));
