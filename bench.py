@@ -104,35 +104,69 @@ def main():
     d_q = torch.from_numpy(qvec).to(dev)
     # one packed result record per rank {keys u64, block i64, doc i32, dist f32}[nq][k]: a single all-gather moves it
     rec = ctx.packed_result_bytes(nq, k)
-    d_pack = torch.empty((rec,), dtype=torch.uint8, device=dev)
     nk = nq * k
-    d_keys = d_pack[0:nk * 8].view(torch.int64).view(nq, k)            # raw u64 ordering keys
-    d_blk = d_pack[nk * 8:nk * 16].view(torch.int64).view(nq, k)
-    d_doc = d_pack[nk * 16:nk * 20].view(torch.int32).view(nq, k)
-    d_dist = d_pack[nk * 20:nk * 24].view(torch.float32).view(nq, k)
+    # N > 1: the exchange + merge of batch i runs on a second stream while batch i+1 is being scanned, so the record and
+    # the gathered buffer are double-buffered.  VSR_BENCH_SIM_WORLD=N (development, N=1 only) drives the same
+    # choreography on one GPU: the "gather" is a device copy into part 0 of an otherwise empty N-part buffer.
+    sim_world = int(os.environ.get("VSR_BENCH_SIM_WORLD", "0")) if world == 1 else 0
+    parts = world if world > 1 else max(sim_world, 1)
+    overlap = parts > 1 and not rehearsal
+    nbuf = 2 if overlap else 1
+
+    def views(pack):
+        return (pack[0:nk * 8].view(torch.int64).view(nq, k),            # raw u64 ordering keys
+                pack[nk * 8:nk * 16].view(torch.int64).view(nq, k),
+                pack[nk * 16:nk * 20].view(torch.int32).view(nq, k),
+                pack[nk * 20:nk * 24].view(torch.float32).view(nq, k))
+
+    d_packs = [torch.empty((rec,), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    d_views = [views(pk) for pk in d_packs]
+    d_keys, d_blk, d_doc, d_dist = d_views[0]
     d_row = torch.empty((nq, k), dtype=torch.int64, device=dev)
     d_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
-    if world > 1:
-        g_pack = torch.empty((world * rec,), dtype=torch.uint8, device=dev)       # [world] packed records
+    if parts > 1:
+        g_packs = [torch.full((parts * rec,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(nbuf)]   # [parts] records
         m_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
         m_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
         m_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
         m_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
         m_keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    if overlap:
+        s_main = torch.cuda.current_stream()
+        s_comm = torch.cuda.Stream(device=dev)
+        mctx = vsrbac.Context(local_rank)                         # the merge runs on the exchange stream
+        mctx.set_stream(s_comm.cuda_stream)
+        ev_scan = [torch.cuda.Event() for _ in range(2)]          # record b holds the results of its batch
+        ev_sent = [torch.cuda.Event() for _ in range(2)]          # record b has been read by the exchange
+    step_no = [0]
 
     def step():
-        corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
-                             ptr(d_cnt), ptr(d_keys))
+        i = step_no[0]
+        step_no[0] += 1
+        b = i % nbuf
+        keys_b, blk_b, doc_b, dist_b = d_views[b]
+        if overlap and i >= 2:
+            s_main.wait_event(ev_sent[b])                         # batch i-2 has left record b
+        corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(blk_b), ptr(doc_b), ptr(d_row), ptr(dist_b),
+                             ptr(d_cnt), ptr(keys_b))
         if world > 1 and rehearsal:
             torch.cuda.synchronize()
             hg = torch.empty((world * rec,), dtype=torch.uint8)
-            dist.all_gather_into_tensor(hg, d_pack.cpu())
-            g_pack.copy_(hg)
-        elif world > 1:
-            dist.all_gather_into_tensor(g_pack, d_pack)           # RCCL over xGMI: nq*k*24 bytes per rank
-        if world > 1:
-            ctx.merge_topk_packed_device(ptr(g_pack), world, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist), ptr(m_keys),
+            dist.all_gather_into_tensor(hg, d_packs[0].cpu())
+            g_packs[0].copy_(hg)
+            ctx.merge_topk_packed_device(ptr(g_packs[0]), world, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist), ptr(m_keys),
                                          ptr(m_cnt))
+        elif overlap:
+            ev_scan[b].record(s_main)
+            with torch.cuda.stream(s_comm):
+                s_comm.wait_event(ev_scan[b])
+                if world > 1:
+                    dist.all_gather_into_tensor(g_packs[b], d_packs[b])   # RCCL over xGMI: nq*k*24 bytes per rank
+                else:
+                    g_packs[b][0:rec].copy_(d_packs[b], non_blocking=True)
+                ev_sent[b].record(s_comm)
+                mctx.merge_topk_packed_device(ptr(g_packs[b]), parts, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist),
+                                              ptr(m_keys), ptr(m_cnt))
 
     def barrier():
         torch.cuda.synchronize()
@@ -231,6 +265,14 @@ def main():
                       f"cores (oracle built with pgvector's flags)",
         }
         out["parity_spot_check"] = {"queries": int(m), "ids_and_distances_identical": ok}
+    if parts > 1:
+        out["config"]["exchange"] = ("all-gather + merge of batch i overlapped with the scan of batch i+1 (second stream)"
+                                     if overlap else "serial (rehearsal through host memory)")
+    if sim_world > 1:      # development check of the overlapped choreography on one GPU
+        last = d_views[(step_no[0] - 1) % nbuf]
+        out["sim_world"] = {"parts": parts, "merged_equals_local": bool(torch.equal(m_keys, last[0]) and
+                                                                        torch.equal(m_blk, last[1]) and
+                                                                        torch.equal(m_dist, last[3]))}
     if rank == 0 and world > 1 and os.environ.get("VSR_BENCH_VERIFY") == "1":
         # rehearsal check: the merged multi-rank result of a few queries against the oracle on the full corpus
         from oracle.oracle import Oracle
@@ -251,6 +293,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     corpus.free()
+    if overlap:
+        mctx.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

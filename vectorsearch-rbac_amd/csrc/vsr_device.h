@@ -5,6 +5,8 @@
 
 namespace vsr {
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;   // native vector: loads as one dwordx4 and stays in registers
+
 constexpr uint64_t KEY_EMPTY = ~0ull;     // sorts after every real key (NaN keys included)
 constexpr int      SCAN_THREADS = 512;    // 8 waves per workgroup
 constexpr int      SCAN_WAVES = SCAN_THREADS / 64;
@@ -168,7 +170,8 @@ inline uint32_t mfma_cap_for_k(uint32_t kp)
 inline int mfma_qmax(uint32_t stride4) { return (stride4 + 15) / 16 <= 4 ? 32 : 16; }
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
-hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 256 | 1024
+hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 64 (one wave per query) | 256 | 1024
+bool select_wave_ok(uint32_t kp, uint64_t max_keys);
 uint32_t select_cap(uint32_t k, int threads);
 hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);
 hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,

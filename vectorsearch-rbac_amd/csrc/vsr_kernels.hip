@@ -112,6 +112,127 @@ __device__ __forceinline__ float output_distance(int metric, float v)
     return metric == M_L2 ? (float) sqrt((double) v) : v;
 }
 
+// What a finished selection (count keys, ascending, in `keys`) turns into: a seed threshold, a partial list for the
+// next stage (level-2 K5 / K5r), or the caller's output rows.  Run by NT cooperating threads (a workgroup or a wave).
+template <int NT>
+__device__ __forceinline__ void select_emit(const SelectParams& p, const SelectQuery& sq, const uint64_t* keys,
+                                            uint32_t count, int tid)
+{
+    const uint32_t k = p.k;
+    if (sq.dst_list == SEL_SEED) {
+        // seed threshold from the sample pass: every row ranking at or before the k-th sampled candidate stays
+        // eligible in the main pass (low word all ones: ties of that distance included); too few samples: no seed
+        if (tid == 0) p.tau_out[sq.out_slot] = count >= k ? (keys[k - 1] | 0xFFFFFFFFull) : KEY_EMPTY;
+        return;
+    }
+    if (sq.dst_list != SEL_FINAL) {                          // level 1 of a two-level merge / K2 survivors for K5r
+        const uint32_t n = count < k ? count : k;
+        uint64_t* dst = p.partial + (size_t) sq.dst_list * p.kp;
+        for (uint32_t i = tid; i < p.kp; i += NT) dst[i] = i < n ? keys[i] : KEY_EMPTY;
+        return;
+    }
+
+    const uint32_t m = count < k ? count : k;
+    const size_t out = (size_t) sq.out_slot * k;
+    for (uint32_t i = tid; i < k; i += NT) {
+        if (i < m) {
+            const uint64_t key = keys[i];
+            const uint32_t row = (uint32_t) key;
+            const float v = mono_to_float((uint32_t) (key >> 32));
+            p.out_block[out + i] = p.block_ids[row];
+            p.out_doc[out + i] = p.doc_ids[row];
+            if (p.out_row) p.out_row[out + i] = p.orig_rows[row];
+            p.out_dist[out + i] = output_distance(p.metric, v);
+            if (p.out_keys) p.out_keys[out + i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t) (row + p.row_offset);
+        } else {
+            p.out_block[out + i] = -1;
+            p.out_doc[out + i] = -1;
+            if (p.out_row) p.out_row[out + i] = -1;
+            p.out_dist[out + i] = __builtin_inff();
+            if (p.out_keys) p.out_keys[out + i] = KEY_EMPTY;
+        }
+    }
+    if (tid == 0) {
+        p.out_count[sq.out_slot] = (int32_t) m;
+        if (p.seeded && m < k && m < sq.allowed) {           // a seeded threshold cut below the k-th result
+            p.out_flags[sq.out_slot] = 1;
+            atomicAdd(p.flagged_total, 1);
+        }
+    }
+}
+
+// Short candidate streams (<= SEL_WAVE_MAX_KEYS keys, kp <= SEL_WAVE_MAX_KP): ONE WAVE per query, four queries per
+// workgroup.  The same threshold-and-compact selection as below, but every step is wave-synchronous: no workgroup
+// barrier anywhere, so a 2000-key merge costs a few microseconds instead of ~150 barrier rounds.
+constexpr uint32_t SEL_WAVE_CAP = 1024;
+__global__ __launch_bounds__(256) void select_wave_kernel(const SelectParams p, uint32_t n_items)
+{
+    __shared__ __align__(16) uint64_t sm_keys[4 * SEL_WAVE_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * 4 + (uint32_t) wave;
+    if (item >= n_items) return;                             // wave-uniform; no workgroup barrier below
+    const SelectQuery sq = p.queries[item];
+    uint64_t* keys = sm_keys + (size_t) wave * SEL_WAVE_CAP;
+    const uint32_t* ids = p.list_ids + sq.ids_begin;
+    const uint32_t kp = p.kp, k = p.k;
+    const uint32_t total = sq.n_lists * kp;
+    const uint32_t trigger = SEL_WAVE_CAP - 64;
+    uint64_t tau = KEY_EMPTY;
+    uint32_t count = 0;                                      // wave-uniform
+
+    auto compact = [&](bool always_sort) {
+        if (count > k || (always_sort && count > 1)) {
+            const uint32_t np2 = next_pow2(count);
+            for (uint32_t i = count + (uint32_t) lane; i < np2; i += 64) keys[i] = KEY_EMPTY;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            bitonic_sort_wave(keys, np2, lane);
+            if (count >= k) {
+                count = k;
+                tau = keys[k - 1];                           // same address in every lane: LDS broadcast
+            }
+        }
+    };
+    // Key i of the query's concatenated lists is partial[ids[i / kp]][i % kp].  Both loads of a batch are issued for
+    // all R keys of a lane before anything waits (no branch around a load: out-of-range slots read key 0 and are
+    // replaced afterwards), so a batch costs two memory round trips, not 2R.
+    constexpr int R = 8;
+    for (uint32_t base = 0; base < total; base += 64 * R) {
+        uint64_t batch[R];
+        uint32_t lid[R], off[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + (uint32_t) (r * 64 + lane);
+            const uint32_t ic = i < total ? i : 0u;
+            const uint32_t j = ic / kp;
+            off[r] = ic - j * kp;
+            lid[r] = ids[j];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) batch[r] = p.partial[(size_t) lid[r] * kp + off[r]];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (base + (uint32_t) (r * 64 + lane) >= total) batch[r] = KEY_EMPTY;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t key = batch[r];
+            const bool pass = key < tau;                     // KEY_EMPTY never passes
+            const uint64_t m = __ballot(pass);
+            if (m) {
+                if (pass) keys[count + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = key;
+                count += (uint32_t) __popcll(m);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (count > trigger) compact(false);
+            }
+        }
+    }
+    compact(true);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    select_emit<64>(p, sq, keys, count, lane);
+}
+
 // NT = 1024 for long candidate streams, 256 for short ones (cheaper barriers, 8 workgroups per CU)
 template <int NT>
 __global__ __launch_bounds__(NT) void select_kernel(const SelectParams p)
@@ -152,46 +273,7 @@ __global__ __launch_bounds__(NT) void select_kernel(const SelectParams p)
     __syncthreads();
     topk_compact<NT>(keys, ctrl, k, tid, true);
 
-    if (sq.dst_list == SEL_SEED) {
-        // seed threshold from the sample pass: every row ranking at or before the k-th sampled candidate stays
-        // eligible in the main pass (low word all ones: ties of that distance included); too few samples: no seed
-        if (tid == 0) p.tau_out[sq.out_slot] = ctrl->count >= k ? (keys[k - 1] | 0xFFFFFFFFull) : KEY_EMPTY;
-        return;
-    }
-    if (sq.dst_list != SEL_FINAL) {                          // level 1 of a two-level merge
-        const uint32_t n = ctrl->count < k ? ctrl->count : k;
-        uint64_t* dst = p.partial + (size_t) sq.dst_list * p.kp;
-        for (uint32_t i = tid; i < p.kp; i += NT) dst[i] = i < n ? keys[i] : KEY_EMPTY;
-        return;
-    }
-
-    const uint32_t m = ctrl->count < k ? ctrl->count : k;
-    const size_t out = (size_t) sq.out_slot * k;
-    for (uint32_t i = tid; i < k; i += NT) {
-        if (i < m) {
-            const uint64_t key = keys[i];
-            const uint32_t row = (uint32_t) key;
-            const float v = mono_to_float((uint32_t) (key >> 32));
-            p.out_block[out + i] = p.block_ids[row];
-            p.out_doc[out + i] = p.doc_ids[row];
-            if (p.out_row) p.out_row[out + i] = p.orig_rows[row];
-            p.out_dist[out + i] = output_distance(p.metric, v);
-            if (p.out_keys) p.out_keys[out + i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t) (row + p.row_offset);
-        } else {
-            p.out_block[out + i] = -1;
-            p.out_doc[out + i] = -1;
-            if (p.out_row) p.out_row[out + i] = -1;
-            p.out_dist[out + i] = __builtin_inff();
-            if (p.out_keys) p.out_keys[out + i] = KEY_EMPTY;
-        }
-    }
-    if (tid == 0) {
-        p.out_count[sq.out_slot] = (int32_t) m;
-        if (p.seeded && m < k && m < sq.allowed) {           // a seeded threshold cut below the k-th result
-            p.out_flags[sq.out_slot] = 1;
-            atomicAdd(p.flagged_total, 1);
-        }
-    }
+    select_emit<NT>(p, sq, keys, ctrl->count, tid);
 }
 
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s)
@@ -206,7 +288,16 @@ hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads,
         hipLaunchKernelGGL(kern, dim3(n_queries), dim3(nt), lds, s, p);
         return hipGetLastError();
     };
+    if (threads == 64) {
+        hipLaunchKernelGGL(select_wave_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, p, n_queries);
+        return hipGetLastError();
+    }
     return threads == 256 ? launch(select_kernel<256>, 256) : launch(select_kernel<1024>, 1024);
+}
+
+bool select_wave_ok(uint32_t kp, uint64_t max_keys)
+{
+    return 2 * kp + 64 <= SEL_WAVE_CAP && max_keys <= 16384;
 }
 
 uint32_t select_cap(uint32_t k, int threads)
@@ -483,23 +574,28 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
     for (int m = 32; m >= 1; m >>= 1) qn_part += __shfl_xor(qn_part, m);
     const float qn = qn_part;
 
-    // half a wave per candidate (32 lanes x float4 = 128 floats per step), two candidates per half-wave in flight:
-    // four independent row gathers per wave hide the HBM/L2 latency of these scattered 512-byte reads
+    // half a wave per candidate (32 lanes x float4 = 128 floats per step), U candidates per half-wave in flight:
+    // 2U independent row gathers per wave hide the HBM/L2 latency of these scattered 512-byte reads
     const int half = lane >> 5, hl = lane & 31;
-    for (uint32_t c0 = (uint32_t) wave * 4; c0 < np2; c0 += 16) {
-        uint64_t sk[2];
-        float s[2] = {0.f, 0.f}, nx[2] = {0.f, 0.f};
+    constexpr int U = 4;                                                   // candidates in flight per half-wave
+    for (uint32_t c0 = (uint32_t) wave * 2 * U; c0 < np2; c0 += 4 * 2 * U) {
+        uint64_t sk[U];
+        float s[U], nx[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) s[u] = nx[u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             const uint32_t c = c0 + 2 * u + half;
             sk[u] = c < p.kp ? list[c] : KEY_EMPTY;
         }
         for (uint32_t ch = hl; ch < p.stride4; ch += 32) {
             const float4 b = q[ch];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (sk[u] == KEY_EMPTY) continue;
-                const float4 a = p.rows[(size_t) (uint32_t) sk[u] * p.stride4 + ch];
+            for (int u = 0; u < U; ++u) {
+                // no branch around the gather (an empty slot reads row 0 and is dropped below): the U loads of a half-
+                // wave must all be in flight before the first FMA waits
+                const f32x4 av = *reinterpret_cast<const f32x4*>(p.rows + (size_t) (sk[u] == KEY_EMPTY ? 0u : (uint32_t) sk[u]) * p.stride4 + ch);
+                const float4 a = make_float4(av[0], av[1], av[2], av[3]);
                 if (p.metric == M_L2) {
                     const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
                     s[u] = fmaf(d0, d0, s[u]); s[u] = fmaf(d1, d1, s[u]); s[u] = fmaf(d2, d2, s[u]); s[u] = fmaf(d3, d3, s[u]);
@@ -513,7 +609,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             for (int m = 16; m >= 1; m >>= 1) {                            // within the half-wave
                 s[u] += __shfl_xor(s[u], m);
                 nx[u] += __shfl_xor(nx[u], m);

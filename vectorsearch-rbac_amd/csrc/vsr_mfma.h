@@ -21,7 +21,6 @@
 
 namespace vsr {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int MF_THREADS = 256;
 constexpr int MF_WAVES = 4;

@@ -1171,7 +1171,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     for (auto& q : plan.selq) max_lists = std::max(max_lists, q.n_lists);
     for (auto& q : plan.sel1) max_lists = std::max(max_lists, q.n_lists);
     for (auto& q : plan.seedq) max_lists = std::max(max_lists, q.n_lists);
-    const int sel_threads = (uint64_t) max_lists * kp <= 16384 ? 256 : 1024;
+    const int sel_threads = select_wave_ok(kp, (uint64_t) max_lists * kp) ? 64 : (uint64_t) max_lists * kp <= 16384 ? 256 : 1024;
     sel.cap = select_cap(kp, sel_threads);
     sel.metric = metric;
     sel.row_offset = (uint32_t) c->row_offset;

@@ -79,16 +79,30 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t n, int
 // order; the wavefront fence keeps the compiler from moving them across the stage boundary).
 __device__ __forceinline__ void bitonic_sort_wave(uint64_t* keys, uint32_t n, int lane)
 {
+    constexpr int B = 4;                           // pairs per lane per batch: all reads of a batch issue before its writes
+    const uint32_t half = n >> 1;
     for (uint32_t size = 2; size <= n; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = (uint32_t) lane; t < (n >> 1); t += 64) {
-                const uint32_t i = 2 * t - (t & (stride - 1));
-                const uint32_t j = i + stride;
-                const bool up = (i & size) == 0;
-                const uint64_t a = keys[i], b = keys[j];
-                if ((a > b) == up) {
-                    keys[i] = b;
-                    keys[j] = a;
+            for (uint32_t t0 = 0; t0 < half; t0 += 64 * B) {
+                uint64_t a[B], b[B];
+                uint32_t ii[B];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const uint32_t t = t0 + (uint32_t) (u * 64 + lane);
+                    ii[u] = 2 * t - (t & (stride - 1));
+                    if (t < half) {
+                        a[u] = keys[ii[u]];
+                        b[u] = keys[ii[u] + stride];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const uint32_t t = t0 + (uint32_t) (u * 64 + lane);
+                    const bool up = (ii[u] & size) == 0;
+                    if (t < half && (a[u] > b[u]) == up) {
+                        keys[ii[u]] = b[u];
+                        keys[ii[u] + stride] = a[u];
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
