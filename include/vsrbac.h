@@ -174,7 +174,7 @@ typedef struct {
     int64_t queries;
 } vsr_stats;
 
-int vsr_profiling(vsr_ctx* ctx, int enable);      /* HIP events around K1 / K5 on the launch stream */
+int vsr_profiling(vsr_ctx* ctx, int enable);      /* HIP events on the launch stream: 1 = around every launch class (scan, sample, K5), 2 = around the main scan launch only, 0 = off */
 int vsr_stats_get(vsr_ctx* ctx, vsr_stats* out);  /* synchronises, accumulates pending events */
 int vsr_stats_reset(vsr_ctx* ctx);
 

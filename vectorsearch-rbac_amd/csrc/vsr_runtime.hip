@@ -4,6 +4,7 @@
 #include "vsr_device.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -127,7 +128,7 @@ struct vsr_ctx {
     hipEvent_t desc_done = nullptr;   // staging buffer reuse guard
     bool desc_pending = false;
     // measurement
-    bool profiling = false;
+    int profiling = 0;             // 0 off, 1 HIP events around every launch class, 2 around the main scan launch only
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> event_pool;
     vsr_stats stats{};
@@ -138,6 +139,8 @@ struct vsr_ctx {
                                    // not raise throughput on MI355X (measured), it only shrinks the algorithmic bytes
     uint32_t debug = 0;            // VSR_DEBUG bits (measurement only)
     double extra_ms[2] = {0, 0};   // sample scan, seed select (profiling only)
+    double host_us[3] = {0, 0, 0}; // VSR_DEBUG: host time in make_plan / waiting for the staging buffer / whole search_impl
+    long   host_calls = 0;
     unsigned long long* d_dbg = nullptr;
     bool no_classes = false;       // VSR_NO_CLASSES=1: scan role partitions whole (A/B measurements)
     bool no_mq = false;            // VSR_NO_MQ=1: keep shared passes on K1 (A/B measurements)
@@ -156,6 +159,9 @@ struct vsr_filter {
     // pre-filter of a role set = union of disjoint permission classes (documents with the same role signature);
     // the planner scans class by class so that queries of different roles share the classes they have in common
     std::vector<vsr_filter*> parts;
+    // planner scratch (one planner per context at a time): group id of this filter in the plan being built
+    mutable uint64_t plan_epoch = 0;
+    mutable uint32_t plan_group = 0;
 };
 
 struct vsr_corpus {
@@ -348,7 +354,7 @@ static void drain_events(vsr_ctx* ctx)
 extern "C" int vsr_profiling(vsr_ctx* ctx, int enable)
 {
     if (!ctx) return fail(VSR_ERR_INVALID, "vsr_profiling: ctx is NULL");
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable < 0 ? 0 : enable;
     return VSR_OK;
 }
 
@@ -364,6 +370,12 @@ extern "C" int vsr_stats_get(vsr_ctx* ctx, vsr_stats* out)
         HIPCHK(hipMemset(ctx->d_dbg, 0, 64));
         fprintf(stderr, "[vsr debug] sample_scan_ms=%.3f seed_select_ms=%.3f\n", ctx->extra_ms[0], ctx->extra_ms[1]);
         ctx->extra_ms[0] = ctx->extra_ms[1] = 0;
+        if (ctx->host_calls)
+            fprintf(stderr, "[vsr debug] host per search: plan %.1f us, staging wait %.1f us, total %.1f us (%ld calls)\n",
+                    ctx->host_us[0] / ctx->host_calls, ctx->host_us[1] / ctx->host_calls, ctx->host_us[2] / ctx->host_calls,
+                    ctx->host_calls);
+        ctx->host_us[0] = ctx->host_us[1] = ctx->host_us[2] = 0;
+        ctx->host_calls = 0;
         fprintf(stderr, "[vsr debug] compactions=%llu appended=%llu tiles=%llu seeds_empty=%llu seeds_set=%llu\n", h[0], h[1],
                 h[2], h[3], h[4]);
     }
@@ -908,6 +920,13 @@ struct Plan {
     uint32_t                 n_partial = 0;  // scan partial lists + level-1 K5 outputs (+ K2 survivor lists)
     int64_t                  scan_rows = 0;
     int64_t                  scan_bytes = 0;
+
+    void reset()                             // keeps the vectors' capacity: one plan per batch, no allocation once warm
+    {
+        q_slots.clear(); groups.clear(); list_ids.clear(); sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
+        n_blocks = 0; qi = 1; mq = false; k2 = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
+        n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0;
+    }
 };
 
 struct PassItem {
@@ -926,17 +945,55 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
     const vsr_ctx* ctx = c->ctx;
     auto fof = [&](uint32_t q) { return filters ? filters[q] : nullptr; };
 
+    // (filter part, query slot) items grouped by part: group ids in first-seen order, then a counting sort (stable, so
+    // the slots of a part stay ascending).  No comparison sort, no per-query allocation: the planner runs once per batch.
+    static thread_local uint64_t epoch = 0;
+    static thread_local std::vector<PassItem> raw, items;
+    static thread_local std::vector<uint32_t> gid, gcount;
+    static thread_local std::vector<const vsr_filter*> gpart;
+    ++epoch;
+    raw.clear(); gid.clear(); gcount.clear(); gpart.clear();
     const bool decompose = nq >= 32 && !ctx->no_classes;
-    std::vector<PassItem> items;
-    items.reserve((size_t) nq * 2);
+    uint32_t null_group = 0xFFFFFFFFu;
+    auto group_of = [&](const vsr_filter* f) -> uint32_t {
+        if (!f) {
+            if (null_group == 0xFFFFFFFFu) {
+                null_group = (uint32_t) gpart.size();
+                gpart.push_back(nullptr);
+                gcount.push_back(0);
+            }
+            return null_group;
+        }
+        if (f->plan_epoch != epoch) {
+            f->plan_epoch = epoch;
+            f->plan_group = (uint32_t) gpart.size();
+            gpart.push_back(f);
+            gcount.push_back(0);
+        }
+        return f->plan_group;
+    };
     for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
         const vsr_filter* f = fof(q);
-        if (decompose && f && !f->parts.empty())
-            for (const vsr_filter* part : f->parts) items.push_back({part, q});
-        else
-            items.push_back({f, q});
+        if (decompose && f && !f->parts.empty()) {
+            for (const vsr_filter* part : f->parts) {
+                const uint32_t g = group_of(part);
+                raw.push_back({part, q});
+                gid.push_back(g);
+                gcount[g]++;
+            }
+        } else {
+            const uint32_t g = group_of(f);
+            raw.push_back({f, q});
+            gid.push_back(g);
+            gcount[g]++;
+        }
     }
-    std::stable_sort(items.begin(), items.end(), [](const PassItem& a, const PassItem& b) { return a.part < b.part; });
+    {
+        uint32_t run = 0;
+        for (auto& cnt : gcount) { const uint32_t n = cnt; cnt = run; run += n; }     // counts -> start offsets
+        items.resize(raw.size());
+        for (size_t i = 0; i < raw.size(); ++i) items[gcount[gid[i]]++] = raw[i];
+    }
 
     const bool mq_ok = mq_supported(c->dim) && mq_qmax(c->dim) >= 4 && !ctx->no_mq;
     // K2: matrix-core screening keeps 2k (>= 32) candidates per query, K5r re-ranks them exactly
@@ -947,7 +1004,8 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
     qmax = qmax >= 4 ? qmax / 4 * 4 : 1;
 
     struct Pass { const vsr_filter* f; uint32_t q_off, q_count; int64_t rows; uint32_t n_tiles; };
-    std::vector<Pass> passes;
+    static thread_local std::vector<Pass> passes;
+    passes.clear();
     uint32_t widest = 1;
     for (size_t s = 0; s < items.size();) {
         size_t e = s;
@@ -980,7 +1038,9 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
     for (auto& p : passes) total_rows += std::max<int64_t>(p.rows, 1);
     const int64_t budget = ctx->block_budget > 0 ? ctx->block_budget : 4 * (int64_t) ctx->prop.multiProcessorCount;
 
-    std::vector<std::vector<uint32_t>> lists_of((size_t) nq), lists_s_of((size_t) nq);
+    // blocks per pass, then the partial lists of every query as CSR (count, prefix, fill): no per-query vectors
+    static thread_local std::vector<uint32_t> loff, lcur, lids, lids_s;
+    loff.assign((size_t) nq + 1, 0);
     for (auto& p : passes) {
         if (p.n_tiles == 0 || p.rows == 0) continue;       // empty filter part: nothing to scan
         int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows - 1) / total_rows;
@@ -1003,11 +1063,7 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
         gs.block_begin = plan.n_blocks_s;
         gs.partial_begin = plan.n_partial_s;
         plan.groups_s.push_back(gs);
-        for (uint32_t qi = 0; qi < p.q_count; ++qi) {
-            const uint32_t slot = plan.q_slots[p.q_off + qi];
-            for (uint32_t b = 0; b < g.n_blocks; ++b) lists_of[slot].push_back(g.partial_begin + qi * g.n_blocks + b);
-            for (uint32_t b = 0; b < gs.n_blocks; ++b) lists_s_of[slot].push_back(gs.partial_begin + qi * gs.n_blocks + b);
-        }
+        for (uint32_t qi = 0; qi < p.q_count; ++qi) loff[plan.q_slots[p.q_off + qi] + 1] += g.n_blocks;
         plan.n_blocks += g.n_blocks;
         plan.n_partial += g.n_blocks * p.q_count;
         plan.n_blocks_s += gs.n_blocks;
@@ -1017,44 +1073,77 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
                            (plan.k2 ? p.rows * 4 : 0);     // K2 also reads |row|^2
     }
     plan.n_scan_lists = plan.n_partial;
+    for (int q = 0; q < nq; ++q) loff[(size_t) q + 1] += loff[(size_t) q];
+    lcur.assign(loff.begin(), loff.end() - 1);
+    lids.resize(loff[(size_t) nq]);
+    const bool same_blocks = SEED_BLOCK_DIV == 1;          // sample lists mirror the main lists one to one
+    if (!same_blocks) lids_s.resize(loff[(size_t) nq]);
+    static thread_local std::vector<uint32_t> lcnt_s;
+    lcnt_s.assign((size_t) nq, 0);
+    for (size_t gi = 0; gi < plan.groups.size(); ++gi) {
+        const ScanGroup& g = plan.groups[gi];
+        const ScanGroup& gs = plan.groups_s[gi];
+        for (uint32_t qi = 0; qi < g.q_count; ++qi) {
+            const uint32_t slot = plan.q_slots[g.q_begin + qi];
+            uint32_t at = lcur[slot];
+            for (uint32_t b = 0; b < g.n_blocks; ++b) lids[at + b] = g.partial_begin + qi * g.n_blocks + b;
+            if (!same_blocks) {
+                // the sample pass has at most as many lists: kept left-packed in the same CSR range
+                uint32_t as = loff[slot] + lcnt_s[slot];
+                for (uint32_t b = 0; b < gs.n_blocks; ++b) lids_s[as + b] = gs.partial_begin + qi * gs.n_blocks + b;
+                lcnt_s[slot] += gs.n_blocks;
+            }
+            lcur[slot] = at + g.n_blocks;
+        }
+    }
 
     // K5 items.  Queries with many partial lists get a first level of SEL_FANIN-list merges.
     plan.selq.resize((size_t) nq);
     plan.seedq.resize((size_t) nq);
+    plan.list_ids.reserve(lids.size() * 2 + 64);
+    static thread_local std::vector<uint32_t> level2;
     for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
         const vsr_filter* f = fof(q);
         const uint32_t allowed = (uint32_t) std::min<int64_t>(f ? f->allowed_rows : c->n, 0xFFFFFFFFll);
-        std::vector<uint32_t>& ls = lists_of[q];
-        if (ls.size() > SEL_FANIN) {
-            std::vector<uint32_t> level2;
-            for (size_t j = 0; j < ls.size(); j += SEL_FANIN) {
+        const uint32_t* ls = lids.data() + loff[q];
+        uint32_t n_ls = loff[q + 1] - loff[q];
+        if (n_ls > SEL_FANIN) {
+            level2.clear();
+            for (uint32_t j = 0; j < n_ls; j += SEL_FANIN) {
                 SelectQuery s1;
                 s1.ids_begin = (uint32_t) plan.list_ids.size();
-                s1.n_lists = (uint32_t) std::min<size_t>(SEL_FANIN, ls.size() - j);
+                s1.n_lists = std::min<uint32_t>(SEL_FANIN, n_ls - j);
                 s1.out_slot = 0;
                 s1.dst_list = plan.n_partial;
                 s1.allowed = 0;
                 s1.pad = 0;
-                plan.list_ids.insert(plan.list_ids.end(), ls.begin() + (long) j, ls.begin() + (long) (j + s1.n_lists));
+                plan.list_ids.insert(plan.list_ids.end(), ls + j, ls + j + s1.n_lists);
                 plan.sel1.push_back(s1);
                 level2.push_back(plan.n_partial++);
             }
-            ls.swap(level2);
+            ls = level2.data();
+            n_ls = (uint32_t) level2.size();
         }
         SelectQuery sq;
         sq.ids_begin = (uint32_t) plan.list_ids.size();
-        sq.n_lists = (uint32_t) ls.size();
+        sq.n_lists = n_ls;
         sq.out_slot = q;
         sq.dst_list = SEL_FINAL;
         sq.allowed = allowed;
         sq.pad = 0;
-        plan.list_ids.insert(plan.list_ids.end(), ls.begin(), ls.end());
+        plan.list_ids.insert(plan.list_ids.end(), ls, ls + n_ls);
         plan.selq[q] = sq;
         SelectQuery sd = sq;                                // seed item: the sample pass's lists of the same query
         sd.ids_begin = (uint32_t) plan.list_ids.size();
-        sd.n_lists = (uint32_t) lists_s_of[q].size();
         sd.dst_list = SEL_SEED;
-        plan.list_ids.insert(plan.list_ids.end(), lists_s_of[q].begin(), lists_s_of[q].end());
+        if (same_blocks) {
+            // identical numbering (partial_begin_s == partial_begin for every pass): reuse the main id range
+            sd.n_lists = loff[q + 1] - loff[q];
+            plan.list_ids.insert(plan.list_ids.end(), lids.data() + loff[q], lids.data() + loff[q + 1]);
+        } else {
+            sd.n_lists = lcnt_s[q];
+            plan.list_ids.insert(plan.list_ids.end(), lids_s.data() + loff[q], lids_s.data() + loff[q] + lcnt_s[q]);
+        }
         plan.seedq[q] = sd;
     }
     if (plan.k2) {          // the final K5 of every query writes its kp screening survivors as list rerank_base + slot
@@ -1072,8 +1161,20 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
                        int32_t* d_cnt, uint64_t* d_keys, bool allow_screening)
 {
     vsr_ctx* ctx = c->ctx;
-    Plan plan;
+    const auto h0 = std::chrono::steady_clock::now();
+    struct HostTimer {
+        vsr_ctx* ctx;
+        std::chrono::steady_clock::time_point t0;
+        ~HostTimer()
+        {
+            ctx->host_us[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            ctx->host_calls++;
+        }
+    } host_timer{ctx, h0};
+    static thread_local Plan plan;
+    plan.reset();
     make_plan(c, nq, k, metric, allow_screening, filters, plan);
+    ctx->host_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
 
     const uint32_t kp = plan.keep;
     const size_t qfloats = (size_t) c->stride4 * 4;
@@ -1094,8 +1195,10 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     if ((rc = ctx->d_desc.reserve(total))) return rc;
     if ((rc = ctx->d_partial.reserve(std::max<size_t>(8, (size_t) plan.n_partial * kp * sizeof(uint64_t))))) return rc;
     if (ctx->desc_pending) {
+        const auto w0 = std::chrono::steady_clock::now();
         HIPCHK(hipEventSynchronize(ctx->desc_done));
         ctx->desc_pending = false;
+        ctx->host_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
     }
     char* hs = ctx->h_desc.as<char>();
     char* ds = ctx->d_desc.as<char>();
@@ -1204,7 +1307,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
         sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_gs);
         sp.n_groups = (uint32_t) plan.groups_s.size();
         hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr;
-        if (ctx->profiling) {
+        if (ctx->profiling == 1) {
             a0 = take_event(ctx); a1 = take_event(ctx); b0 = take_event(ctx); b1 = take_event(ctx);
             HIPCHK(hipEventRecord(a0, ctx->stream));
         }
@@ -1255,7 +1358,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
 
     sel.k = kp;
     hipEvent_t s0 = nullptr, s1 = nullptr;
-    if (ctx->profiling) {
+    if (ctx->profiling == 1) {
         s0 = take_event(ctx);
         s1 = take_event(ctx);
         HIPCHK(hipEventRecord(s0, ctx->stream));

@@ -56,7 +56,8 @@ class Context:
         check(self._lib.vsr_synchronize(self._h))
 
     def profiling(self, enable=True):
-        check(self._lib.vsr_profiling(self._h, int(bool(enable))))
+        """True / 1: HIP events around every launch class; 2: around the main scan launch only; False: off."""
+        check(self._lib.vsr_profiling(self._h, int(enable)))
 
     def stats(self):
         st = _ffi.Stats()
@@ -215,9 +216,19 @@ class Corpus:
         return Filter(self, h, owned=True)
 
     # ---- search ------------------------------------------------------------------------------
+    def pack_filters(self, filters):
+        """One filter per query as a reusable C array (build it once when the same batch shape repeats)."""
+        arr = (C.c_void_p * len(filters))(*[(f._h if f is not None else None) for f in filters])
+        arr._keep = list(filters)                    # the handles must outlive the array
+        return arr
+
     def _filter_array(self, filters, nq):
         if filters is None:
             return None, None
+        if isinstance(filters, C.Array):
+            if len(filters) != nq:
+                raise ValueError("one filter per query")
+            return filters, filters
         if isinstance(filters, Filter):
             filters = [filters] * nq
         if len(filters) != nq:
