@@ -171,7 +171,7 @@ inline int mfma_qmax(uint32_t stride4) { return (stride4 + 15) / 16 <= 4 ? 32 : 
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 64 (one wave per query) | 256 | 1024
-bool select_wave_ok(uint32_t kp, uint64_t max_keys);
+uint32_t select_wave_fanin(uint32_t kp);
 uint32_t select_cap(uint32_t k, int threads);
 hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);
 hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,

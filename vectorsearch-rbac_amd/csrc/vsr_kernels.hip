@@ -161,76 +161,135 @@ __device__ __forceinline__ void select_emit(const SelectParams& p, const SelectQ
     }
 }
 
-// Short candidate streams (<= SEL_WAVE_MAX_KEYS keys, kp <= SEL_WAVE_MAX_KP): ONE WAVE per query, four queries per
-// workgroup.  The same threshold-and-compact selection as below, but every step is wave-synchronous: no workgroup
-// barrier anywhere, so a 2000-key merge costs a few microseconds instead of ~150 barrier rounds.
-constexpr uint32_t SEL_WAVE_CAP = 1024;
-__global__ __launch_bounds__(256) void select_wave_kernel(const SelectParams p, uint32_t n_items)
+// Short candidate sets (<= 64 lists, <= 64 * R keys): ONE WAVE per query, four queries per workgroup, every key of
+// the query in registers.  The k smallest are found by an MSB-first radix select (8-bit digits, histogram in LDS,
+// wave-wide prefix sum): no sorting network, no workgroup barrier.  Only the caller-visible output (SEL_FINAL) is
+// sorted afterwards, and then only its k keys.
+constexpr uint32_t SEL_WAVE_MAX_K = 512;
+template <int R>
+__global__ __launch_bounds__(256) void select_radix_kernel(const SelectParams p, uint32_t n_items)
 {
-    __shared__ __align__(16) uint64_t sm_keys[4 * SEL_WAVE_CAP];
+    __shared__ uint32_t sm_hist[4][256];
+    __shared__ __align__(16) uint64_t sm_out[4][SEL_WAVE_MAX_K];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t item = blockIdx.x * 4 + (uint32_t) wave;
     if (item >= n_items) return;                             // wave-uniform; no workgroup barrier below
     const SelectQuery sq = p.queries[item];
-    uint64_t* keys = sm_keys + (size_t) wave * SEL_WAVE_CAP;
-    const uint32_t* ids = p.list_ids + sq.ids_begin;
+    uint32_t* hist = sm_hist[wave];
     const uint32_t kp = p.kp, k = p.k;
-    const uint32_t total = sq.n_lists * kp;
-    const uint32_t trigger = SEL_WAVE_CAP - 64;
-    uint64_t tau = KEY_EMPTY;
-    uint32_t count = 0;                                      // wave-uniform
+    const uint32_t total = sq.n_lists * kp;                  // <= 64 * R (launcher contract)
+    const uint32_t my_list = (uint32_t) lane < sq.n_lists ? p.list_ids[sq.ids_begin + (uint32_t) lane] : 0u;
 
-    auto compact = [&](bool always_sort) {
-        if (count > k || (always_sort && count > 1)) {
-            const uint32_t np2 = next_pow2(count);
-            for (uint32_t i = count + (uint32_t) lane; i < np2; i += 64) keys[i] = KEY_EMPTY;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            bitonic_sort_wave(keys, np2, lane);
-            if (count >= k) {
-                count = k;
-                tau = keys[k - 1];                           // same address in every lane: LDS broadcast
-            }
-        }
-    };
-    // Key i of the query's concatenated lists is partial[ids[i / kp]][i % kp].  Both loads of a batch are issued for
-    // all R keys of a lane before anything waits (no branch around a load: out-of-range slots read key 0 and are
-    // replaced afterwards), so a batch costs two memory round trips, not 2R.
-    constexpr int R = 8;
-    for (uint32_t base = 0; base < total; base += 64 * R) {
-        uint64_t batch[R];
-        uint32_t lid[R], off[R];
+    // key i of the concatenated lists = partial[list j = i / kp][i % kp]; list ids come from lane j's register, so a
+    // chunk of C keys per lane costs one memory round trip
+    uint64_t reg[R];
+    constexpr int C = R < 16 ? R : 16;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = base + (uint32_t) (r * 64 + lane);
+    for (int c0 = 0; c0 < R; c0 += C) {
+        uint32_t src[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const uint32_t i = (uint32_t) ((c0 + c) * 64 + lane);
             const uint32_t ic = i < total ? i : 0u;
             const uint32_t j = ic / kp;
-            off[r] = ic - j * kp;
-            lid[r] = ids[j];
+            src[c] = (uint32_t) __shfl((int) my_list, (int) j) * kp + (ic - j * kp);
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r) batch[r] = p.partial[(size_t) lid[r] * kp + off[r]];
+        for (int c = 0; c < C; ++c) reg[c0 + c] = p.partial[src[c]];
+    }
+    uint32_t n_real = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (base + (uint32_t) (r * 64 + lane) >= total) batch[r] = KEY_EMPTY;
+    for (int r = 0; r < R; ++r) {
+        if ((uint32_t) (r * 64 + lane) >= total) reg[r] = KEY_EMPTY;
+        n_real += (uint32_t) __popcll(__ballot(reg[r] != KEY_EMPTY));
+    }
+
+    // ---- radix select: tau = the need-th smallest real key ----
+    const uint32_t want = n_real < k ? n_real : k;
+    uint64_t tau = KEY_EMPTY - 1;                            // want == n_real: every real key
+    if (n_real > k) {
+        uint64_t prefix = 0, mask = 0;
+        uint32_t need = k;
+        for (int shift = 56; shift >= 0; shift -= 8) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint64_t key = batch[r];
-            const bool pass = key < tau;                     // KEY_EMPTY never passes
-            const uint64_t m = __ballot(pass);
-            if (m) {
-                if (pass) keys[count + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = key;
-                count += (uint32_t) __popcll(m);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (count > trigger) compact(false);
+            for (int t = 0; t < 4; ++t) hist[t * 64 + lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (reg[r] != KEY_EMPTY && (reg[r] & mask) == prefix) atomicAdd(&hist[(uint32_t) (reg[r] >> shift) & 255u], 1u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 h = *reinterpret_cast<const uint4*>(&hist[4 * lane]);       // bins 4*lane .. 4*lane+3
+            const uint32_t s4 = h.x + h.y + h.z + h.w;
+            uint32_t incl = s4;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t) __shfl_up((int) incl, d);
+                if (lane >= d) incl += o;
             }
+            const uint64_t reach = __ballot(incl >= need);                          // non-empty: the total is n >= need
+            const int L = __ffsll((unsigned long long) reach) - 1;
+            uint32_t before = incl - s4, digit = 4u * (uint32_t) lane, cnt = h.x;
+            if (before + h.x < need) { before += h.x; digit += 1; cnt = h.y;
+                if (before + h.y < need) { before += h.y; digit += 1; cnt = h.z;
+                    if (before + h.z < need) { before += h.z; digit += 1; cnt = h.w; } } }
+            before = (uint32_t) __shfl((int) before, L);
+            digit = (uint32_t) __shfl((int) digit, L);
+            cnt = (uint32_t) __shfl((int) cnt, L);
+            need -= before;
+            prefix |= (uint64_t) digit << shift;
+            mask |= 0xFFull << shift;
+            if (cnt == need) {                               // the whole bin is wanted: no need to look at lower digits
+                tau = prefix | ((1ull << shift) - 1ull);
+                break;
+            }
+            tau = prefix;                                    // shift == 0 ends here (keys are unique: cnt == need == 1)
         }
     }
-    compact(true);
+    // the largest selected key (exact k-th smallest when n_real >= k)
+    uint64_t kth = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (reg[r] <= tau && reg[r] != KEY_EMPTY && reg[r] > kth) kth = reg[r];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) kth, d), hi = (uint32_t) __shfl_xor((int) (uint32_t) (kth >> 32), d);
+        const uint64_t o = ((uint64_t) hi << 32) | lo;
+        kth = o > kth ? o : kth;
+    }
+
+    if (sq.dst_list == SEL_SEED) {
+        // seed threshold from the sample pass: every row ranking at or before the k-th sampled candidate stays
+        // eligible in the main pass (low word all ones: ties of that distance included); too few samples: no seed
+        if (lane == 0) p.tau_out[sq.out_slot] = n_real >= k ? (kth | 0xFFFFFFFFull) : KEY_EMPTY;
+        return;
+    }
+
+    // compaction of the selected keys; the largest goes last (K5r reads it as the worst kept screening value)
+    const bool to_list = sq.dst_list != SEL_FINAL;
+    uint64_t* dst = to_list ? p.partial + (size_t) sq.dst_list * kp : sm_out[wave];
+    const bool full = n_real >= k && want > 0;
+    uint32_t at = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool sel = reg[r] != KEY_EMPTY && reg[r] <= tau && !(full && reg[r] == kth);
+        const uint64_t m = __ballot(sel);
+        if (sel) dst[at + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = reg[r];
+        at += (uint32_t) __popcll(m);
+    }
+    if (full && lane == 0) dst[want - 1] = kth;
+    if (to_list) {
+        for (uint32_t i = want + (uint32_t) lane; i < kp; i += 64) dst[i] = KEY_EMPTY;
+        return;
+    }
+    // caller-visible rows: sort the k selected keys, then the shared output stage
+    const uint32_t np2 = next_pow2(want);
+    for (uint32_t i = want + (uint32_t) lane; i < np2; i += 64) dst[i] = KEY_EMPTY;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    select_emit<64>(p, sq, keys, count, lane);
+    if (want > 1) bitonic_sort_wave(dst, np2, lane);
+    select_emit<64>(p, sq, dst, want, lane);
 }
 
 // NT = 1024 for long candidate streams, 256 for short ones (cheaper barriers, 8 workgroups per CU)
@@ -288,16 +347,23 @@ hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads,
         hipLaunchKernelGGL(kern, dim3(n_queries), dim3(nt), lds, s, p);
         return hipGetLastError();
     };
-    if (threads == 64) {
-        hipLaunchKernelGGL(select_wave_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, p, n_queries);
+    if (threads == 64) {                                     // one wave per query; p.cap carries the key capacity 64 * R
+        const dim3 grid((n_queries + 3) / 4), block(256);
+        if (p.cap <= 1024) hipLaunchKernelGGL(select_radix_kernel<16>, grid, block, 0, s, p, n_queries);
+        else if (p.cap <= 2048) hipLaunchKernelGGL(select_radix_kernel<32>, grid, block, 0, s, p, n_queries);
+        else if (p.cap <= 4096) hipLaunchKernelGGL(select_radix_kernel<64>, grid, block, 0, s, p, n_queries);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     return threads == 256 ? launch(select_kernel<256>, 256) : launch(select_kernel<1024>, 1024);
 }
 
-bool select_wave_ok(uint32_t kp, uint64_t max_keys)
+// Fan-in (lists per K5 item) of the one-wave-per-query selection for lists of kp keys, 0 if it does not apply.
+uint32_t select_wave_fanin(uint32_t kp)
 {
-    return 2 * kp + 64 <= SEL_WAVE_CAP && max_keys <= 16384;
+    if (kp > SEL_WAVE_MAX_K) return 0;
+    const uint32_t f = 4096u / kp;
+    return f >= 8 ? (f < 64 ? f : 64u) : 0u;
 }
 
 uint32_t select_cap(uint32_t k, int threads)

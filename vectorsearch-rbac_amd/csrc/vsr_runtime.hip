@@ -918,6 +918,7 @@ struct Plan {
     uint32_t                 n_blocks_s = 0;
     uint32_t                 n_partial_s = 0;
     uint32_t                 n_partial = 0;  // scan partial lists + level-1 K5 outputs (+ K2 survivor lists)
+    bool                     sel_wave = false;  // K5 items are small enough for the one-wave-per-query radix select
     int64_t                  scan_rows = 0;
     int64_t                  scan_bytes = 0;
 
@@ -925,7 +926,7 @@ struct Plan {
     {
         q_slots.clear(); groups.clear(); list_ids.clear(); sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
         n_blocks = 0; qi = 1; mq = false; k2 = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
-        n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0;
+        n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0; sel_wave = false;
     }
 };
 
@@ -1097,7 +1098,13 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
         }
     }
 
-    // K5 items.  Queries with many partial lists get a first level of SEL_FANIN-list merges.
+    // K5 items.  Queries with many partial lists get a first level of fan-in-list merges.  When every query fits two
+    // levels of the wave-per-query selection (<= 4096 keys per item) that kernel and its smaller fan-in are used.
+    uint32_t most_lists = 0;
+    for (int q = 0; q < nq; ++q) most_lists = std::max(most_lists, loff[(size_t) q + 1] - loff[(size_t) q]);
+    const uint32_t wave_fanin = select_wave_fanin(plan.keep);
+    plan.sel_wave = wave_fanin > 0 && (uint64_t) most_lists <= (uint64_t) wave_fanin * wave_fanin;
+    const uint32_t fanin = plan.sel_wave ? wave_fanin : SEL_FANIN;
     plan.selq.resize((size_t) nq);
     plan.seedq.resize((size_t) nq);
     plan.list_ids.reserve(lids.size() * 2 + 64);
@@ -1107,12 +1114,12 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
         const uint32_t allowed = (uint32_t) std::min<int64_t>(f ? f->allowed_rows : c->n, 0xFFFFFFFFll);
         const uint32_t* ls = lids.data() + loff[q];
         uint32_t n_ls = loff[q + 1] - loff[q];
-        if (n_ls > SEL_FANIN) {
+        if (n_ls > fanin) {
             level2.clear();
-            for (uint32_t j = 0; j < n_ls; j += SEL_FANIN) {
+            for (uint32_t j = 0; j < n_ls; j += fanin) {
                 SelectQuery s1;
                 s1.ids_begin = (uint32_t) plan.list_ids.size();
-                s1.n_lists = std::min<uint32_t>(SEL_FANIN, n_ls - j);
+                s1.n_lists = std::min<uint32_t>(fanin, n_ls - j);
                 s1.out_slot = 0;
                 s1.dst_list = plan.n_partial;
                 s1.allowed = 0;
@@ -1136,14 +1143,10 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
         SelectQuery sd = sq;                                // seed item: the sample pass's lists of the same query
         sd.ids_begin = (uint32_t) plan.list_ids.size();
         sd.dst_list = SEL_SEED;
-        if (same_blocks) {
-            // identical numbering (partial_begin_s == partial_begin for every pass): reuse the main id range
-            sd.n_lists = loff[q + 1] - loff[q];
-            plan.list_ids.insert(plan.list_ids.end(), lids.data() + loff[q], lids.data() + loff[q + 1]);
-        } else {
-            sd.n_lists = lcnt_s[q];
-            plan.list_ids.insert(plan.list_ids.end(), lids_s.data() + loff[q], lids_s.data() + loff[q] + lcnt_s[q]);
-        }
+        const uint32_t* sl = same_blocks ? lids.data() + loff[q] : lids_s.data() + loff[q];
+        sd.n_lists = same_blocks ? loff[q + 1] - loff[q] : lcnt_s[q];     // same_blocks: identical list numbering
+        if (plan.sel_wave && sd.n_lists > 64) sd.n_lists = 64;            // a subset of the sample only loosens the seed
+        plan.list_ids.insert(plan.list_ids.end(), sl, sl + sd.n_lists);
         plan.seedq[q] = sd;
     }
     if (plan.k2) {          // the final K5 of every query writes its kp screening survivors as list rerank_base + slot
@@ -1273,9 +1276,11 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     uint32_t max_lists = 1;
     for (auto& q : plan.selq) max_lists = std::max(max_lists, q.n_lists);
     for (auto& q : plan.sel1) max_lists = std::max(max_lists, q.n_lists);
-    for (auto& q : plan.seedq) max_lists = std::max(max_lists, q.n_lists);
-    const int sel_threads = select_wave_ok(kp, (uint64_t) max_lists * kp) ? 64 : (uint64_t) max_lists * kp <= 16384 ? 256 : 1024;
-    sel.cap = select_cap(kp, sel_threads);
+    uint32_t max_seed_lists = 1;
+    for (auto& q : plan.seedq) max_seed_lists = std::max(max_seed_lists, q.n_lists);
+    if (!plan.sel_wave) max_lists = std::max(max_lists, max_seed_lists);
+    const int sel_threads = plan.sel_wave ? 64 : (uint64_t) max_lists * kp <= 16384 ? 256 : 1024;
+    sel.cap = plan.sel_wave ? std::max<uint32_t>(1024, max_lists * kp) : select_cap(kp, sel_threads);   // wave: key capacity
     sel.metric = metric;
     sel.row_offset = (uint32_t) c->row_offset;
     sel.block_ids = c->d_block;
@@ -1295,7 +1300,14 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     // ---- threshold seeding: a 1/SEED_STRIDE sample pass of the same launch, then the m-th best sampled candidate of
     // each query becomes the initial threshold of the main pass (all rows at or before it stay eligible; a query whose
     // seed turns out too tight is flagged by K5 / K5r and re-run unseeded) ----
+    // m-th best of a 1/SEED_STRIDE sample: mean lambda = kp / SEED_STRIDE rows of the true top-kp fall into the
+    // sample; lambda + 6 sigma + 4 makes a too-tight seed a ~1e-8 event (and a detected one: K5 / K5r flag it).
+    // The m-th best of the whole sample only involves the m best of every sample list, so those lists are short.
+    const double lambda = (double) kp / SEED_STRIDE;
+    const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
+    constexpr uint32_t SEED_LIST = 32;                      // keys a sample-pass workgroup publishes per query
     const bool seed = allow_screening && ctx->seeding && (plan.k2 || plan.mq) && plan.n_blocks > 0 &&
+                      seed_m <= SEED_LIST && kp >= SEED_LIST &&
                       plan.scan_rows >= ctx->seed_min_rows &&
                       plan.scan_rows / (int64_t) std::max<size_t>(1, plan.groups.size()) >= ctx->seed_min_pass_rows;
     sp.sample_stride = 1;
@@ -1311,22 +1323,23 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
             a0 = take_event(ctx); a1 = take_event(ctx); b0 = take_event(ctx); b1 = take_event(ctx);
             HIPCHK(hipEventRecord(a0, ctx->stream));
         }
+        sp.kp = sp.k = SEED_LIST;
         if (plan.k2) HIPCHK(launch_mfma(sp, metric, plan.n_blocks_s, ctx->stream));
         else HIPCHK(launch_mq(sp, metric, plan.n_blocks_s, ctx->stream));
+        sp.kp = sp.k = kp;
         if (a0) {
             HIPCHK(hipEventRecord(a1, ctx->stream));
             HIPCHK(hipEventRecord(b0, ctx->stream));
         }
         sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
         sp.n_groups = (uint32_t) plan.groups.size();
-        // m-th best of a 1/SEED_STRIDE sample: mean lambda = kp / SEED_STRIDE rows of the true top-kp fall into the
-        // sample; lambda + 6 sigma + 4 makes a too-tight seed a ~1e-8 event (and a detected one: K5 / K5r flag it)
-        const double lambda = (double) kp / SEED_STRIDE;
-        const uint32_t m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
-        sel.k = std::min(m, kp);
-        sel.tau_out = ctx->d_tau.as<uint64_t>();
-        sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sd);
-        HIPCHK(launch_select(sel, (uint32_t) plan.seedq.size(), sel_threads, ctx->stream));
+        SelectParams seeds = sel;
+        seeds.kp = SEED_LIST;
+        seeds.k = seed_m;
+        if (plan.sel_wave) seeds.cap = std::max<uint32_t>(1024, max_seed_lists * SEED_LIST);   // <= 64 lists (planner)
+        seeds.tau_out = ctx->d_tau.as<uint64_t>();
+        seeds.queries = reinterpret_cast<const SelectQuery*>(ds + off_sd);
+        HIPCHK(launch_select(seeds, (uint32_t) plan.seedq.size(), sel_threads, ctx->stream));
         if (a0) {
             HIPCHK(hipEventRecord(b1, ctx->stream));
             ctx->pending.push_back({a0, a1, 3});
