@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void select_radix_kernel(const SelectParams p,
     // key i of the concatenated lists = partial[list j = i / kp][i % kp]; list ids come from lane j's register, so a
     // chunk of C keys per lane costs one memory round trip
     uint64_t reg[R];
-    constexpr int C = R < 16 ? R : 16;
+    constexpr int C = R < 32 ? R : 32;
 #pragma unroll
     for (int c0 = 0; c0 < R; c0 += C) {
         uint32_t src[C];
@@ -204,60 +204,9 @@ __global__ __launch_bounds__(256) void select_radix_kernel(const SelectParams p,
         n_real += (uint32_t) __popcll(__ballot(reg[r] != KEY_EMPTY));
     }
 
-    // ---- radix select: tau = the need-th smallest real key ----
     const uint32_t want = n_real < k ? n_real : k;
-    uint64_t tau = KEY_EMPTY - 1;                            // want == n_real: every real key
-    if (n_real > k) {
-        uint64_t prefix = 0, mask = 0;
-        uint32_t need = k;
-        for (int shift = 56; shift >= 0; shift -= 8) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) hist[t * 64 + lane] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (reg[r] != KEY_EMPTY && (reg[r] & mask) == prefix) atomicAdd(&hist[(uint32_t) (reg[r] >> shift) & 255u], 1u);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint4 h = *reinterpret_cast<const uint4*>(&hist[4 * lane]);       // bins 4*lane .. 4*lane+3
-            const uint32_t s4 = h.x + h.y + h.z + h.w;
-            uint32_t incl = s4;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = (uint32_t) __shfl_up((int) incl, d);
-                if (lane >= d) incl += o;
-            }
-            const uint64_t reach = __ballot(incl >= need);                          // non-empty: the total is n >= need
-            const int L = __ffsll((unsigned long long) reach) - 1;
-            uint32_t before = incl - s4, digit = 4u * (uint32_t) lane, cnt = h.x;
-            if (before + h.x < need) { before += h.x; digit += 1; cnt = h.y;
-                if (before + h.y < need) { before += h.y; digit += 1; cnt = h.z;
-                    if (before + h.z < need) { before += h.z; digit += 1; cnt = h.w; } } }
-            before = (uint32_t) __shfl((int) before, L);
-            digit = (uint32_t) __shfl((int) digit, L);
-            cnt = (uint32_t) __shfl((int) cnt, L);
-            need -= before;
-            prefix |= (uint64_t) digit << shift;
-            mask |= 0xFFull << shift;
-            if (cnt == need) {                               // the whole bin is wanted: no need to look at lower digits
-                tau = prefix | ((1ull << shift) - 1ull);
-                break;
-            }
-            tau = prefix;                                    // shift == 0 ends here (keys are unique: cnt == need == 1)
-        }
-    }
-    // the largest selected key (exact k-th smallest when n_real >= k)
-    uint64_t kth = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (reg[r] <= tau && reg[r] != KEY_EMPTY && reg[r] > kth) kth = reg[r];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) kth, d), hi = (uint32_t) __shfl_xor((int) (uint32_t) (kth >> 32), d);
-        const uint64_t o = ((uint64_t) hi << 32) | lo;
-        kth = o > kth ? o : kth;
-    }
+    uint64_t tau, kth;
+    wave_radix_select<R>(reg, n_real, k, hist, lane, tau, kth);
 
     if (sq.dst_list == SEL_SEED) {
         // seed threshold from the sample pass: every row ranking at or before the k-th sampled candidate stays
@@ -269,16 +218,7 @@ __global__ __launch_bounds__(256) void select_radix_kernel(const SelectParams p,
     // compaction of the selected keys; the largest goes last (K5r reads it as the worst kept screening value)
     const bool to_list = sq.dst_list != SEL_FINAL;
     uint64_t* dst = to_list ? p.partial + (size_t) sq.dst_list * kp : sm_out[wave];
-    const bool full = n_real >= k && want > 0;
-    uint32_t at = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const bool sel = reg[r] != KEY_EMPTY && reg[r] <= tau && !(full && reg[r] == kth);
-        const uint64_t m = __ballot(sel);
-        if (sel) dst[at + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = reg[r];
-        at += (uint32_t) __popcll(m);
-    }
-    if (full && lane == 0) dst[want - 1] = kth;
+    wave_emit_selected<R>(reg, n_real, k, tau, kth, dst, lane);
     if (to_list) {
         for (uint32_t i = want + (uint32_t) lane; i < kp; i += 64) dst[i] = KEY_EMPTY;
         return;
@@ -643,7 +583,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
     // half a wave per candidate (32 lanes x float4 = 128 floats per step), U candidates per half-wave in flight:
     // 2U independent row gathers per wave hide the HBM/L2 latency of these scattered 512-byte reads
     const int half = lane >> 5, hl = lane & 31;
-    constexpr int U = 4;                                                   // candidates in flight per half-wave
+    constexpr int U = 8;                                                   // candidates in flight per half-wave
     for (uint32_t c0 = (uint32_t) wave * 2 * U; c0 < np2; c0 += 4 * 2 * U) {
         uint64_t sk[U];
         float s[U], nx[U];

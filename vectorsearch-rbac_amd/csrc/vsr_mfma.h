@@ -15,6 +15,7 @@
 // -> 4 x 16-row sub-tiles x 4 k-steps of MFMA per float4.  The 16 query vectors sit in registers as B fragments
 // for the whole kernel when d <= 256 (32 VGPRs at d = 128), else they are re-read from LDS.
 #pragma once
+#include <type_traits>
 #include "vsr_device.h"
 #include "vsr_scan.h"
 #include "vsr_topk.h"
@@ -373,25 +374,39 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     }
 
     __syncthreads();
-    if (cap <= (uint32_t) (64 * MF_S * 16 / 8)) {
-        // publish, one wave per query: each wave sorts inside its own staging image, no workgroup barriers
-        uint64_t* wbuf = reinterpret_cast<uint64_t*>(stage);
+    constexpr int PR = 32;                                                     // candidate keys per lane at publish
+    if (cap <= (uint32_t) (64 * PR)) {
+        // publish, one wave per query: the candidates of a (workgroup, query) buffer go to registers and the `keep`
+        // smallest are picked by a radix select (vsr_topk.h) -- no sort, no workgroup barrier.  The partial list is
+        // unordered; K5 selects again and only the final answer is sorted.
+        uint32_t* hist = reinterpret_cast<uint32_t*>(stage);                   // wave-private, the image is dead by now
         for (uint32_t q = (uint32_t) wave; q < q_count; q += MF_WAVES) {
             const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
             const uint64_t* cq = cand + (size_t) q * cand_qstride;
             uint64_t* dst = p.partial + (size_t) (grp.partial_begin + q * grp.n_blocks + local_block) * p.kp;
-            if (n <= keep) {                                                   // nothing to drop: order is K5's job
+            if (n <= keep) {                                                   // nothing to drop
                 for (uint32_t i = (uint32_t) lane; i < p.kp; i += 64) dst[i] = i < n ? cq[i] : KEY_EMPTY;
                 continue;
             }
-            const uint32_t np2 = next_pow2(n);
-            for (uint32_t i = (uint32_t) lane; i < np2; i += 64) wbuf[i] = i < n ? cq[i] : KEY_EMPTY;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            bitonic_sort_wave(wbuf, np2, lane);
-            for (uint32_t i = (uint32_t) lane; i < p.kp; i += 64) dst[i] = i < keep ? wbuf[i] : KEY_EMPTY;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            auto pick = [&](auto rc) {                                         // RR keys per lane cover the n candidates
+                constexpr int RR = decltype(rc)::value;
+                uint64_t reg[RR];
+#pragma unroll
+                for (int r = 0; r < RR; ++r) {
+                    const uint32_t i = (uint32_t) (r * 64 + lane);
+                    reg[r] = cq[i < n ? i : 0u];
+                }
+#pragma unroll
+                for (int r = 0; r < RR; ++r)
+                    if ((uint32_t) (r * 64 + lane) >= n) reg[r] = KEY_EMPTY;
+                uint64_t tsel, kth;
+                wave_radix_select<RR>(reg, n, keep, hist, lane, tsel, kth);
+                const uint32_t want = wave_emit_selected<RR>(reg, n, keep, tsel, kth, dst, lane);
+                for (uint32_t i = want + (uint32_t) lane; i < p.kp; i += 64) dst[i] = KEY_EMPTY;
+            };
+            if (n <= 256) pick(std::integral_constant<int, 4>{});
+            else if (n <= 512) pick(std::integral_constant<int, 8>{});
+            else pick(std::integral_constant<int, PR>{});
         }
         return;
     }

@@ -116,6 +116,103 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t v)
     return v <= 2 ? 2u : 1u << (32 - __clz(v - 1));
 }
 
+// Wave-level selection without sorting: the wave holds R keys per lane in registers (KEY_EMPTY = no key, n_real real
+// ones in total).  tau = a threshold such that exactly min(k, n_real) real keys are <= tau; kth = the largest of those
+// (the exact k-th smallest when n_real >= k).  MSB-first radix select over 8-bit digits; `hist` = 256 wave-private
+// LDS words.  Keys are unique, so the selection is exact.
+template <int R>
+__device__ __forceinline__ void wave_radix_select(const uint64_t (&reg)[R], uint32_t n_real, uint32_t k, uint32_t* hist,
+                                                  int lane, uint64_t& tau, uint64_t& kth)
+{
+    tau = KEY_EMPTY - 1;                                     // n_real <= k: every real key
+    if (n_real > k) {
+        // digits every key agrees on carry no information (and would serialise all 64 lanes on one histogram bin):
+        // start at the highest byte in which two keys differ
+        uint64_t all_and = ~0ull, all_or = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (reg[r] != KEY_EMPTY) { all_and &= reg[r]; all_or |= reg[r]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t al = (uint32_t) __shfl_xor((int) (uint32_t) all_and, d), ah = (uint32_t) __shfl_xor((int) (uint32_t) (all_and >> 32), d);
+            const uint32_t ol = (uint32_t) __shfl_xor((int) (uint32_t) all_or, d), oh = (uint32_t) __shfl_xor((int) (uint32_t) (all_or >> 32), d);
+            all_and &= ((uint64_t) ah << 32) | al;
+            all_or |= ((uint64_t) oh << 32) | ol;
+        }
+        const uint64_t diff = all_and ^ all_or;              // non-zero: n_real > k >= 1 distinct keys
+        const int top = (63 - __clzll((long long) diff)) >> 3 << 3;               // shift of the first useful digit
+        uint64_t mask = top >= 56 ? 0ull : ~0ull << (top + 8);
+        uint64_t prefix = all_or & mask;
+        uint32_t need = k;
+        for (int shift = top; shift >= 0; shift -= 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hist[t * 64 + lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (reg[r] != KEY_EMPTY && (reg[r] & mask) == prefix) atomicAdd(&hist[(uint32_t) (reg[r] >> shift) & 255u], 1u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 h = *reinterpret_cast<const uint4*>(&hist[4 * lane]);       // bins 4*lane .. 4*lane+3
+            const uint32_t s4 = h.x + h.y + h.z + h.w;
+            uint32_t incl = s4;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t) __shfl_up((int) incl, d);
+                if (lane >= d) incl += o;
+            }
+            const uint64_t reach = __ballot(incl >= need);                          // non-empty: the total is >= need
+            const int L = __ffsll((unsigned long long) reach) - 1;
+            uint32_t before = incl - s4, digit = 4u * (uint32_t) lane, cnt = h.x;
+            if (before + h.x < need) { before += h.x; digit += 1; cnt = h.y;
+                if (before + h.y < need) { before += h.y; digit += 1; cnt = h.z;
+                    if (before + h.z < need) { before += h.z; digit += 1; cnt = h.w; } } }
+            before = (uint32_t) __shfl((int) before, L);
+            digit = (uint32_t) __shfl((int) digit, L);
+            cnt = (uint32_t) __shfl((int) cnt, L);
+            need -= before;
+            prefix |= (uint64_t) digit << shift;
+            mask |= 0xFFull << shift;
+            tau = prefix;                                    // shift == 0 ends here (keys are unique: cnt == need == 1)
+            if (cnt == need) {                               // the whole bin is wanted: no need to look at lower digits
+                tau = prefix | ((1ull << shift) - 1ull);
+                break;
+            }
+        }
+    }
+    kth = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (reg[r] <= tau && reg[r] != KEY_EMPTY && reg[r] > kth) kth = reg[r];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) kth, d), hi = (uint32_t) __shfl_xor((int) (uint32_t) (kth >> 32), d);
+        const uint64_t o = ((uint64_t) hi << 32) | lo;
+        kth = o > kth ? o : kth;
+    }
+}
+
+// Writes the selected keys (see wave_radix_select) to dst[0 .. want), unordered except that the largest one goes last
+// when the selection is full (n_real >= k).  Returns want = min(k, n_real).
+template <int R>
+__device__ __forceinline__ uint32_t wave_emit_selected(const uint64_t (&reg)[R], uint32_t n_real, uint32_t k, uint64_t tau,
+                                                       uint64_t kth, uint64_t* dst, int lane)
+{
+    const uint32_t want = n_real < k ? n_real : k;
+    const bool full = n_real >= k && want > 0;
+    uint32_t at = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool sel = reg[r] != KEY_EMPTY && reg[r] <= tau && !(full && reg[r] == kth);
+        const uint64_t m = __ballot(sel);
+        if (sel) dst[at + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = reg[r];
+        at += (uint32_t) __popcll(m);
+    }
+    if (full && lane == 0) dst[want - 1] = kth;
+    return want;
+}
+
 // Keep the k smallest keys (sorted) and lower tau.  Must be called by all threads, after a barrier
 // that orders every append before it.  `always_sort` forces sorted output even when count <= k.
 template <int NT>
