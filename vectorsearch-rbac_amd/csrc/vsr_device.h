@@ -173,6 +173,20 @@ hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipSt
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 64 (one wave per query) | 256 | 1024
 uint32_t select_wave_fanin(uint32_t kp);
 uint32_t select_cap(uint32_t k, int threads);
+// Per-batch staging (one launch): descriptor block host -> device, queries padded to the row stride, |q|^2, flag / seed init.
+struct StageParams {
+    const uint4* src16;            // pinned host memory as the device sees it
+    uint4*       dst16;
+    uint32_t     n16;              // 16-byte units
+    const float* q_src;            // nq x q_stride floats (caller's device buffer: q_stride = dim; staged host copy: qfloats)
+    uint32_t     q_stride;
+    float*       q_dst;            // nq x qfloats, zero padded
+    uint32_t     dim, qfloats, nq;
+    float*       q_norm2;          // [nq]
+    int32_t*     flags;            // [nq] <- 0
+    uint64_t*    tau;              // [nq] <- KEY_EMPTY (no seed)
+};
+hipError_t launch_stage(const StageParams& p, hipStream_t s);
 hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);
 hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,
                                uint32_t words, const uint64_t* user_mask, uint64_t* bitmap, hipStream_t s);

@@ -450,6 +450,44 @@ hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride
     return hipGetLastError();
 }
 
+// Per-batch staging, see StageParams.  Workgroups [0, nq): one query each; the rest copy the descriptor block.
+__global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
+{
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= p.nq) {
+        const uint32_t nb = gridDim.x - p.nq;
+        for (uint32_t i = (blockIdx.x - p.nq) * 256 + (uint32_t) tid; i < p.n16; i += nb * 256) p.dst16[i] = p.src16[i];
+        return;
+    }
+    const uint32_t s = blockIdx.x;
+    const float* src = p.q_src + (size_t) s * p.q_stride;
+    float* dst = p.q_dst + (size_t) s * p.qfloats;
+    for (uint32_t j = (uint32_t) tid; j < p.qfloats; j += 256) dst[j] = j < p.dim ? src[j] : 0.0f;
+    if (tid == 0) {
+        p.flags[s] = 0;
+        p.tau[s] = KEY_EMPTY;
+    }
+    __syncthreads();
+    if (tid < 64) {                                          // the arithmetic of row_norms_kernel, one wave per row
+        const float4* row = reinterpret_cast<const float4*>(dst);
+        float acc = 0.0f;
+        for (uint32_t c = (uint32_t) tid; c < p.qfloats / 4; c += 64) {
+            const float4 x = row[c];
+            acc = fmaf(x.x, x.x, acc); acc = fmaf(x.y, x.y, acc); acc = fmaf(x.z, x.z, acc); acc = fmaf(x.w, x.w, acc);
+        }
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+        if (tid == 0) p.q_norm2[s] = acc;
+    }
+}
+
+hipError_t launch_stage(const StageParams& p, hipStream_t s)
+{
+    const uint32_t copy_blocks = p.n16 ? (p.n16 + 1023) / 1024 < 64 ? (p.n16 + 1023) / 1024 : 64 : 0;
+    if (p.nq + copy_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_kernel, dim3(p.nq + copy_blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------------------------
 // Permission bitmaps.  allowed(user,row) <=> docmask[doc(row)] & usermask != 0
 // (row_level_security.py:54-65 with PermissionAssignment folded into per-document role bitsets).

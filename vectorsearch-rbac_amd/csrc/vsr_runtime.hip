@@ -86,7 +86,8 @@ struct PinBuf {
         cap = 0;
         size_t want = std::max(bytes, (size_t) 4096);
         want += want / 4;
-        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&p, want, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(&dp, p, 0));
         cap = want;
         return VSR_OK;
     }
@@ -94,9 +95,11 @@ struct PinBuf {
     {
         if (p) (void) hipHostFree(p);
         p = nullptr;
+        dp = nullptr;
         cap = 0;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    void* dp = nullptr;            // the same memory as the device sees it (kernels read the staging block directly)
 };
 
 struct EventPair {
@@ -1194,15 +1197,17 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     const size_t total = align_up(off_li + plan.list_ids.size() * sizeof(uint32_t), 256);
 
     int rc;
-    if ((rc = ctx->h_desc.reserve(total))) return rc;
-    if ((rc = ctx->d_desc.reserve(total))) return rc;
-    if ((rc = ctx->d_partial.reserve(std::max<size_t>(8, (size_t) plan.n_partial * kp * sizeof(uint64_t))))) return rc;
-    if (ctx->desc_pending) {
+    if (ctx->desc_pending) {       // the previous batch's staging kernel still owns the pinned block
         const auto w0 = std::chrono::steady_clock::now();
         HIPCHK(hipEventSynchronize(ctx->desc_done));
         ctx->desc_pending = false;
         ctx->host_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
     }
+    if ((rc = ctx->h_desc.reserve(total))) return rc;
+    if ((rc = ctx->d_desc.reserve(total))) return rc;
+    if ((rc = ctx->d_partial.reserve(std::max<size_t>(8, (size_t) plan.n_partial * kp * sizeof(uint64_t))))) return rc;
+    if ((rc = ctx->d_flags.reserve((size_t) nq * sizeof(int32_t)))) return rc;
+    if ((rc = ctx->d_tau.reserve((size_t) nq * sizeof(uint64_t)))) return rc;
     char* hs = ctx->h_desc.as<char>();
     char* ds = ctx->d_desc.as<char>();
     if (h_queries) {
@@ -1220,13 +1225,25 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     memcpy(hs + off_sq, plan.selq.data(), plan.selq.size() * sizeof(SelectQuery));
     memcpy(hs + off_sd, plan.seedq.data(), plan.seedq.size() * sizeof(SelectQuery));
     memcpy(hs + off_li, plan.list_ids.data(), plan.list_ids.size() * sizeof(uint32_t));
-    if (h_queries) {
-        HIPCHK(hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        HIPCHK(hipMemcpyAsync(ds + off_g, hs + off_g, total - off_g, hipMemcpyHostToDevice, ctx->stream));
-        // pad the caller's device queries to the row stride (slot = query index)
-        HIPCHK(launch_gather_queries(d_queries, nullptr, (uint32_t) nq, (uint32_t) dim, (uint32_t) qfloats,
-                                     reinterpret_cast<float*>(ds + off_q), ctx->stream));
+    {
+        // ONE staging kernel instead of an SDMA copy + gather + norm + two fills: it pulls the descriptor block out of
+        // the pinned host buffer, pads the queries to the row stride (from the caller's device buffer, or from the
+        // staged host copy), computes |q|^2 with the arithmetic of the row norms, clears the per-query flags and seeds.
+        StageParams st;
+        const char* hd = reinterpret_cast<const char*>(ctx->h_desc.dp);
+        st.src16 = reinterpret_cast<const uint4*>(hd + off_g);
+        st.dst16 = reinterpret_cast<uint4*>(ds + off_g);
+        st.n16 = (uint32_t) ((total - off_g) / 16);
+        st.q_src = d_queries ? d_queries : reinterpret_cast<const float*>(hd + off_q);
+        st.q_stride = d_queries ? (uint32_t) dim : (uint32_t) qfloats;
+        st.q_dst = reinterpret_cast<float*>(ds + off_q);
+        st.dim = (uint32_t) dim;
+        st.qfloats = (uint32_t) qfloats;
+        st.nq = (uint32_t) nq;
+        st.q_norm2 = reinterpret_cast<float*>(ds + off_qn);
+        st.flags = ctx->d_flags.as<int32_t>();
+        st.tau = ctx->d_tau.as<uint64_t>();
+        HIPCHK(launch_stage(st, ctx->stream));
     }
     HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
     ctx->desc_pending = true;
@@ -1262,11 +1279,6 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
     sp.n_groups = (uint32_t) plan.groups.size();
     sp.q_slots = reinterpret_cast<const uint32_t*>(ds + off_qs);
-    if ((rc = ctx->d_flags.reserve((size_t) nq * sizeof(int32_t)))) return rc;
-    HIPCHK(hipMemsetAsync(ctx->d_flags.p, 0, (size_t) nq * sizeof(int32_t), ctx->stream));
-    if (metric == VSR_METRIC_COSINE || plan.k2)   // |q|^2 with the same kernel that made the row norms
-        HIPCHK(launch_row_norms(reinterpret_cast<const float4*>(sp.queries), (uint32_t) nq, c->stride4,
-                                reinterpret_cast<float*>(ds + off_qn), ctx->stream));
 
     SelectParams sel;
     sel.partial = ctx->d_partial.as<uint64_t>();
@@ -1313,8 +1325,6 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sp.sample_stride = 1;
     sp.tau_init = nullptr;
     if (seed) {
-        if ((rc = ctx->d_tau.reserve((size_t) nq * sizeof(uint64_t)))) return rc;
-        HIPCHK(hipMemsetAsync(ctx->d_tau.p, 0xFF, (size_t) nq * sizeof(uint64_t), ctx->stream));   // no seed by default
         sp.sample_stride = SEED_STRIDE;
         sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_gs);
         sp.n_groups = (uint32_t) plan.groups_s.size();
