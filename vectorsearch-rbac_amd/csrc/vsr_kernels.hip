@@ -620,8 +620,12 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
 
     // half a wave per candidate (32 lanes x float4 = 128 floats per step), U candidates per half-wave in flight:
     // 2U independent row gathers per wave hide the HBM/L2 latency of these scattered 512-byte reads
+    // the survivors' screening keys first (one round trip for the whole list, not one per gather round); the exact
+    // keys overwrite them slot by slot: every slot is read by the half-wave that later writes it
+    for (uint32_t c = (uint32_t) tid; c < np2; c += 256) keys[c] = c < p.kp ? list[c] : KEY_EMPTY;
+    __syncthreads();
     const int half = lane >> 5, hl = lane & 31;
-    constexpr int U = 8;                                                   // candidates in flight per half-wave
+    constexpr int U = 4;                                                   // candidates in flight per half-wave
     for (uint32_t c0 = (uint32_t) wave * 2 * U; c0 < np2; c0 += 4 * 2 * U) {
         uint64_t sk[U];
         float s[U], nx[U];
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t c = c0 + 2 * u + half;
-            sk[u] = c < p.kp ? list[c] : KEY_EMPTY;
+            sk[u] = c < np2 ? keys[c] : KEY_EMPTY;
         }
         for (uint32_t ch = hl; ch < p.stride4; ch += 32) {
             const float4 b = q[ch];
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
         int flag = 0;
         // every row outside the kept set ranks at or after `bound` in screening value: the worst kept candidate when
         // the list is full, else the seeded threshold (if any), else there is no outside row at all
-        const uint64_t worst_kept = list[p.kp - 1];                        // screening keys are ascending
+        const uint64_t worst_kept = list[p.kp - 1];                        // K5 leaves the largest kept key last
         uint64_t bound = worst_kept;
         if (bound == KEY_EMPTY && p.seeded) bound = p.tau_init[slot];
         if (bound != KEY_EMPTY) {

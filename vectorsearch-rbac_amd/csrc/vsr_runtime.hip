@@ -1317,7 +1317,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     // The m-th best of the whole sample only involves the m best of every sample list, so those lists are short.
     const double lambda = (double) kp / SEED_STRIDE;
     const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
-    constexpr uint32_t SEED_LIST = 32;                      // keys a sample-pass workgroup publishes per query
+    constexpr uint32_t SEED_LIST = 64;                      // keys a sample-pass workgroup publishes per query (one tile: no selection)
     const bool seed = allow_screening && ctx->seeding && (plan.k2 || plan.mq) && plan.n_blocks > 0 &&
                       seed_m <= SEED_LIST && kp >= SEED_LIST &&
                       plan.scan_rows >= ctx->seed_min_rows &&
