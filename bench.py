@@ -243,6 +243,26 @@ def main():
         "screening_flagged_queries": int(flagged_total),
     }
 
+    # ---- latency mode (informational, N = 1): the harness's call shape, one query per call ----
+    if world == 1 and sim_world <= 1:
+        m1 = min(200, nq)
+        singles = [corpus.pack_filters([filters._keep[i]]) for i in range(m1)]
+        for i in range(8):
+            corpus.search_device(ptr(d_q[i:i + 1]), 1, k, "l2", singles[i], ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
+                                 ptr(d_cnt), ptr(d_keys))
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for i in range(m1):
+            corpus.search_device(ptr(d_q[i:i + 1]), 1, k, "l2", singles[i], ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
+                                 ptr(d_cnt), ptr(d_keys))
+        torch.cuda.synchronize()
+        tl = time.perf_counter() - tl
+        out["single_query_mode"] = {"queries": m1, "ms_per_query": round(tl / m1 * 1e3, 4), "qps": round(m1 / tl, 1),
+                                    "note": "one query per call, back to back on one stream (K1 path); not the headline"}
+        corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
+                             ptr(d_cnt), ptr(d_keys))       # leave the batch result in place for the parity spot check
+        torch.cuda.synchronize()
+
     # ---- CPU baseline (rank 0, N = 1): the oracle, pgvector's flags, one thread, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle

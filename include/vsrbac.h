@@ -172,6 +172,7 @@ typedef struct {
     int64_t select_launches;    /* K5 */
     double  select_ms;
     int64_t queries;
+    double  search_ms;          /* profiling level 1: device time of whole searches, staging kernel to last output kernel */
 } vsr_stats;
 
 int vsr_profiling(vsr_ctx* ctx, int enable);      /* HIP events on the launch stream: 1 = around every launch class (scan, sample, K5), 2 = around the main scan launch only, 0 = off */

@@ -104,7 +104,7 @@ struct PinBuf {
 
 struct EventPair {
     hipEvent_t a, b;
-    int kind;   // 0 = scan (1 query/pass), 1 = scan (shared pass), 2 = select
+    int kind;   // 0 = scan (1 query/pass), 1 = scan (shared pass), 2 = select, 3 = sample scan, 4 = seed select, 5 = whole search
 };
 
 struct vsr_ctx {
@@ -338,7 +338,9 @@ static void drain_events(vsr_ctx* ctx)
     for (auto& ep : ctx->pending) {
         float ms = 0.f;
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
-            if (ep.kind >= 3) {
+            if (ep.kind == 5) {
+                ctx->stats.search_ms += ms;
+            } else if (ep.kind >= 3) {
                 ctx->extra_ms[ep.kind - 3] += ms;
             } else if (ep.kind < 2) {
                 ctx->stats.scan_ms[ep.kind] += ms;
@@ -1225,6 +1227,12 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     memcpy(hs + off_sq, plan.selq.data(), plan.selq.size() * sizeof(SelectQuery));
     memcpy(hs + off_sd, plan.seedq.data(), plan.seedq.size() * sizeof(SelectQuery));
     memcpy(hs + off_li, plan.list_ids.data(), plan.list_ids.size() * sizeof(uint32_t));
+    hipEvent_t w0 = nullptr, w1 = nullptr;                  // profiling level 1: the whole search on the device
+    if (ctx->profiling == 1) {
+        w0 = take_event(ctx);
+        w1 = take_event(ctx);
+        HIPCHK(hipEventRecord(w0, ctx->stream));
+    }
     {
         // ONE staging kernel instead of an SDMA copy + gather + norm + two fills: it pulls the descriptor block out of
         // the pinned host buffer, pads the queries to the row stride (from the caller's device buffer, or from the
@@ -1423,6 +1431,10 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     if (s0) {
         HIPCHK(hipEventRecord(s1, ctx->stream));
         ctx->pending.push_back({s0, s1, 2});
+    }
+    if (w0) {
+        HIPCHK(hipEventRecord(w1, ctx->stream));
+        ctx->pending.push_back({w0, w1, 5});
     }
     ctx->stats.queries += nq;
     return VSR_OK;

@@ -18,7 +18,7 @@ class VsrError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("scan_launches", C.c_int64 * 2), ("scan_ms", C.c_double * 2), ("scan_bytes", C.c_int64 * 2),
                 ("scan_rows", C.c_int64 * 2), ("select_launches", C.c_int64), ("select_ms", C.c_double),
-                ("queries", C.c_int64)]
+                ("queries", C.c_int64), ("search_ms", C.c_double)]
 
 
 # every symbol include/vsrbac.h declares: name -> (restype, argtypes)

@@ -113,7 +113,7 @@ class Deployment:
         res = fn()
         st = self.ctx.stats()
         self.ctx.profiling(False)
-        return res, (sum(st["scan_ms"]) + st["select_ms"]) * 1e-3
+        return res, st["search_ms"] * 1e-3
 
     # ---- ROLE pre-filter ---------------------------------------------------------------------
     def search_documents_role_partition(self, user_id, query_vector, topk=5, statistics_type="sql"):
