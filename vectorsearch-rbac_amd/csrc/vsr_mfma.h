@@ -307,7 +307,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                 const uint32_t qi = (uint32_t) (g * MF_NQ + jq);
                 const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[qi].tau);
                 const bool qok = qi < q_count && !(p.debug & 1u);
-                uint64_t keyv[16];
+                // screening test in float: a value is a candidate unless it is greater than the threshold's distance
+                // (NaN values and an open / NaN threshold pass).  That admits a superset of `key < tau` (ties of the
+                // threshold distance): extra candidates are harmless, a missing one is not.  The 64-bit key is only
+                // built for the few survivors.
+                const bool open = tau == KEY_EMPTY;
+                const float tau_f = mono_to_float((uint32_t) (tau >> 32));
+                float vv[16];
                 uint32_t pmask = 0;
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
@@ -318,8 +324,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = screen_value<METRIC>(acc[g][sub][r], nx4[r], my_qn[g]);
-                        keyv[sub * 4 + r] = make_key(v, (uint32_t) rows4[r]);
-                        if (qok && rows4[r] >= 0 && keyv[sub * 4 + r] < tau) pmask |= 1u << (sub * 4 + r);
+                        vv[sub * 4 + r] = v;
+                        if (qok && rows4[r] >= 0 && (open || !(v > tau_f))) pmask |= 1u << (sub * 4 + r);
                     }
                 }
                 if (__ballot(pmask != 0) != 0) {                               // wave-uniform
@@ -333,7 +339,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                     uint64_t* dst = cand + (size_t) qi * cand_qstride + base;
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        if ((pmask & (1u << i)) && !(p.debug & 32u)) dst[__popc(pmask & ((1u << i) - 1u))] = keyv[i];
+                        if (pmask & (1u << i)) {                               // the key is built for survivors only
+                            const int32_t row = ridx[(i >> 2) * 16 + kq * 4 + (i & 3)];
+                            dst[__popc(pmask & ((1u << i) - 1u))] = make_key(vv[i], (uint32_t) row);
+                        }
                 }
             }
         } else {
