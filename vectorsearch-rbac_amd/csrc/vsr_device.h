@@ -52,6 +52,8 @@ struct ScanParams {
     const uint64_t*  tau_init;     // [n_slots] seeded thresholds (sample pass), nullptr = none
     uint32_t         sample_stride;  // 1 = every tile; S > 1 = sample pass over every S-th tile of each workgroup
     uint32_t         debug;        // measurement only: bit 0 = never append candidates (isolates the streaming/compute part)
+    const uint2*     block_map;    // shared-pass launches: workgroup -> (group, block of the group); x == ~0u: idle
+                                   // workgroup.  nullptr: groups own contiguous workgroup ranges (block_begin)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
     unsigned long long* dbg;       // measurement only (VSR_DEBUG bit 1): [0] compactions, [1] appended keys, [2] tiles
 };

@@ -49,13 +49,23 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    uint32_t lo = 0, hi = p.n_groups;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (p.groups[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
+    // workgroup -> (pass, block of the pass): through the planner's XCD-aware map (passes that read the same rows get
+    // the same workgroup id modulo 8, i.e. one XCD and one L2, and neighbouring dispatch slots), else by block range
+    uint32_t lo = 0, mapped_block = 0;
+    if (p.block_map) {
+        const uint2 m = p.block_map[blockIdx.x];
+        if (m.x == 0xFFFFFFFFu) return;                                        // padding workgroup of a short XCD lane
+        lo = m.x;
+        mapped_block = m.y;
+    } else {
+        uint32_t hi = p.n_groups;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (p.groups[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
+        }
     }
     const ScanGroup grp = p.groups[lo];
-    const uint32_t local_block = blockIdx.x - grp.block_begin;
+    const uint32_t local_block = p.block_map ? mapped_block : blockIdx.x - grp.block_begin;
 
     const uint32_t stride4 = p.stride4, cap = p.cap, keep = p.k;
     const uint32_t nstage = (stride4 + MF_S - 1) / MF_S;

@@ -146,6 +146,7 @@ struct vsr_ctx {
     long   host_calls = 0;
     unsigned long long* d_dbg = nullptr;
     bool no_classes = false;       // VSR_NO_CLASSES=1: scan role partitions whole (A/B measurements)
+    bool no_xcd_map = false;       // VSR_NO_XCD_MAP=1: workgroups in pass order instead of XCD-aware bundles (A/B)
     bool no_mq = false;            // VSR_NO_MQ=1: keep shared passes on K1 (A/B measurements)
 };
 
@@ -252,6 +253,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
+    if ((env = getenv("VSR_NO_XCD_MAP"))) ctx->no_xcd_map = atoi(env) != 0;
     if ((env = getenv("VSR_SEED_MIN_PASS"))) ctx->seed_min_pass_rows = atoll(env);
     if ((env = getenv("VSR_SEED_STRIDE"))) SEED_STRIDE = (uint32_t) std::max(2, atoi(env));
     if ((env = getenv("VSR_SEED_DIV"))) SEED_BLOCK_DIV = (uint32_t) std::max(1, atoi(env));
@@ -924,12 +926,14 @@ struct Plan {
     uint32_t                 n_partial_s = 0;
     uint32_t                 n_partial = 0;  // scan partial lists + level-1 K5 outputs (+ K2 survivor lists)
     bool                     sel_wave = false;  // K5 items are small enough for the one-wave-per-query radix select
+    std::vector<uint2>       block_map;      // shared-pass launches: workgroup -> (group, block), XCD-aware (see make_plan)
+    uint32_t                 n_launch = 0;   // workgroups of the main launch (= block_map.size() when mapped)
     int64_t                  scan_rows = 0;
     int64_t                  scan_bytes = 0;
 
     void reset()                             // keeps the vectors' capacity: one plan per batch, no allocation once warm
     {
-        q_slots.clear(); groups.clear(); list_ids.clear(); sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
+        q_slots.clear(); groups.clear(); list_ids.clear(); block_map.clear(); n_launch = 0; sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
         n_blocks = 0; qi = 1; mq = false; k2 = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
         n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0; sel_wave = false;
     }
@@ -1079,6 +1083,38 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
                            (plan.k2 ? p.rows * 4 : 0);     // K2 also reads |row|^2
     }
     plan.n_scan_lists = plan.n_partial;
+    plan.n_launch = plan.n_blocks;
+    if (plan.k2 || plan.mq) {
+        // XCD-aware workgroup order.  Consecutive passes over the same rows (one permission class scanned for several
+        // query groups) are split into the same block ranges; block j of all of them forms a bundle that should run on
+        // ONE XCD at the same time, so that the rows are fetched over the fabric once and re-read from that XCD's L2.
+        // Workgroups are dealt round-robin over the 8 XCDs (id % 8 = one XCD, MI355X_MICROARCH.md): lane l owns the
+        // ids l, l+8, l+16, ...; every bundle is appended whole to the currently shortest lane.
+        constexpr uint32_t XCDS = 8;
+        static thread_local std::vector<uint2> lane[XCDS];
+        for (auto& l : lane) l.clear();
+        size_t gi = 0;
+        while (gi < plan.groups.size()) {
+            size_t ge = gi + 1;
+            while (ge < plan.groups.size() && plan.groups[ge].tiles == plan.groups[gi].tiles &&
+                   plan.groups[ge].bitmap == plan.groups[gi].bitmap && plan.groups[ge].n_tiles == plan.groups[gi].n_tiles &&
+                   plan.groups[ge].n_blocks == plan.groups[gi].n_blocks)
+                ++ge;
+            for (uint32_t j = 0; j < plan.groups[gi].n_blocks; ++j) {
+                uint32_t best = 0;
+                for (uint32_t l = 1; l < XCDS; ++l)
+                    if (lane[l].size() < lane[best].size()) best = l;
+                for (size_t g2 = gi; g2 < ge; ++g2) lane[best].push_back(make_uint2((uint32_t) g2, j));
+            }
+            gi = ge;
+        }
+        size_t longest = 0;
+        for (auto& l : lane) longest = std::max(longest, l.size());
+        plan.block_map.assign(longest * XCDS, make_uint2(0xFFFFFFFFu, 0u));
+        for (uint32_t l = 0; l < XCDS; ++l)
+            for (size_t t = 0; t < lane[l].size(); ++t) plan.block_map[t * XCDS + l] = lane[l][t];
+        plan.n_launch = (uint32_t) plan.block_map.size();
+    }
     for (int q = 0; q < nq; ++q) loff[(size_t) q + 1] += loff[(size_t) q];
     lcur.assign(loff.begin(), loff.end() - 1);
     lids.resize(loff[(size_t) nq]);
@@ -1196,7 +1232,8 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     const size_t off_sq = align_up(off_s1 + plan.sel1.size() * sizeof(SelectQuery), 256);
     const size_t off_sd = align_up(off_sq + plan.selq.size() * sizeof(SelectQuery), 256);
     const size_t off_li = align_up(off_sd + plan.seedq.size() * sizeof(SelectQuery), 256);
-    const size_t total = align_up(off_li + plan.list_ids.size() * sizeof(uint32_t), 256);
+    const size_t off_bm = align_up(off_li + plan.list_ids.size() * sizeof(uint32_t), 256);
+    const size_t total = align_up(off_bm + plan.block_map.size() * sizeof(uint2), 256);
 
     int rc;
     if (ctx->desc_pending) {       // the previous batch's staging kernel still owns the pinned block
@@ -1227,6 +1264,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     memcpy(hs + off_sq, plan.selq.data(), plan.selq.size() * sizeof(SelectQuery));
     memcpy(hs + off_sd, plan.seedq.data(), plan.seedq.size() * sizeof(SelectQuery));
     memcpy(hs + off_li, plan.list_ids.data(), plan.list_ids.size() * sizeof(uint32_t));
+    memcpy(hs + off_bm, plan.block_map.data(), plan.block_map.size() * sizeof(uint2));
     hipEvent_t w0 = nullptr, w1 = nullptr;                  // profiling level 1: the whole search on the device
     if (ctx->profiling == 1) {
         w0 = take_event(ctx);
@@ -1272,6 +1310,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     sp.cand = nullptr;
     sp.debug = ctx->debug;
     sp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;    // bounds-guard word (checked by vsr_screening_check)
+    sp.block_map = nullptr;
     sp.dbg = nullptr;
     if (ctx->debug & 2u) {
         if (!ctx->d_dbg) {
@@ -1376,8 +1415,10 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
             e1 = take_event(ctx);
             HIPCHK(hipEventRecord(e0, ctx->stream));
         }
-        if (plan.k2) HIPCHK(launch_mfma(sp, metric, plan.n_blocks, ctx->stream));
-        else if (plan.mq) HIPCHK(launch_mq(sp, metric, plan.n_blocks, ctx->stream));
+        if (!plan.block_map.empty() && !ctx->no_xcd_map) sp.block_map = reinterpret_cast<const uint2*>(ds + off_bm);
+        const uint32_t launch_blocks = sp.block_map ? plan.n_launch : plan.n_blocks;
+        if (plan.k2) HIPCHK(launch_mfma(sp, metric, launch_blocks, ctx->stream));
+        else if (plan.mq) HIPCHK(launch_mq(sp, metric, launch_blocks, ctx->stream));
         else HIPCHK(launch_scan(sp, metric, c->dim, plan.qi, plan.n_blocks, ctx->stream));
         if (e0) {
             HIPCHK(hipEventRecord(e1, ctx->stream));
