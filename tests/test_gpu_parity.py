@@ -341,6 +341,36 @@ def test_k_range(ctx, oracle, k):
     corpus.free()
 
 
+def test_many_partial_lists_take_two_select_levels(ctx, oracle):
+    """48 unfiltered queries over 300k rows: every pass is cut into ~146 workgroups, so a query owns far more partial
+    lists than one wave-per-query selection holds (fan-in 20 at k = 100) and K5 runs in two levels; the seeded main
+    launch, the XCD-aware workgroup order and a reusable filter array (all None here) ride along."""
+    rng = np.random.default_rng(41)
+    n, nq, k = 300_000, 48, 100
+    x = sift_like(rng, n)
+    blk, doc = _ids(n, 100)
+    corpus = ctx.load_corpus(x, blk, doc)
+    qrows = rng.integers(0, n, nq)
+    q = x[qrows] + rng.integers(-3, 4, (nq, x.shape[1])).astype(np.float32)      # still integer-valued: exact sums
+    res = corpus.search(q, k, "l2")
+    for i in range(0, nq, 5):
+        _expect_exact(oracle, res, i, "l2", x, q[i], k, doc, blk)
+    # the same batch again through one class-decomposed role filter per query (shared tile lists + bitmap-free ranges)
+    perms = [(1, d) for d in range(1, n // 100 + 1, 3)] + [(2, d) for d in range(2, n // 100 + 1, 3)]
+    corpus.load_rbac([(u, 1 + u % 2) for u in range(1, 9)] + [(8, 2)], perms)   # user 8 holds both roles
+    users = rng.integers(1, 9, nq)
+    farr = corpus.pack_filters([corpus.filter_for_user(int(u)) for u in users])
+    res = corpus.search(q, k, "l2", farr)
+    urole = {u: {1 + u % 2} for u in range(1, 9)}
+    urole[8].add(2)
+    docs_of = {1: set(d for r, d in perms if r == 1), 2: set(d for r, d in perms if r == 2)}
+    for i in range(0, nq, 7):
+        vis = set().union(*[docs_of[r] for r in urole[int(users[i])]])
+        mask = np.isin(doc, np.fromiter(vis, dtype=np.int32)).astype(np.uint8)
+        _expect_exact(oracle, res, i, "l2", x, q[i], k, doc, blk, mask)
+    corpus.free()
+
+
 def test_k_larger_than_rows_and_empty(ctx, oracle):
     import vsrbac
     rng = np.random.default_rng(6)

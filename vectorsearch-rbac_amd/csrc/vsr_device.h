@@ -200,7 +200,4 @@ hipError_t launch_merge_lists(const uint64_t* keys, const int64_t* blocks, const
                               uint32_t n_parts, uint32_t n_queries, uint32_t k, size_t part_stride, int64_t* out_block,
                               int32_t* out_doc, float* out_dist, uint64_t* out_keys, int32_t* out_count,
                               hipStream_t s);
-hipError_t launch_gather_queries(const float* src, const uint32_t* slot_query, uint32_t nq, uint32_t dim,
-                                 uint32_t qfloats, float* dst, hipStream_t s);
-
 }  // namespace vsr

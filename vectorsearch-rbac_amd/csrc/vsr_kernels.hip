@@ -768,21 +768,4 @@ hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipSt
     return hipGetLastError();
 }
 
-// queries handed over in device memory: gather into slot order, zero-padded to the row stride
-__global__ __launch_bounds__(256) void gather_queries_kernel(const float* src, const uint32_t* slot_query, uint32_t nq,
-                                                             uint32_t dim, uint32_t qfloats, float* dst)
-{
-    const uint32_t s = blockIdx.x;
-    const float* q = src + (size_t) (slot_query ? slot_query[s] : s) * dim;
-    for (uint32_t j = threadIdx.x; j < qfloats; j += 256) dst[(size_t) s * qfloats + j] = j < dim ? q[j] : 0.0f;
-}
-
-hipError_t launch_gather_queries(const float* src, const uint32_t* slot_query, uint32_t nq, uint32_t dim,
-                                 uint32_t qfloats, float* dst, hipStream_t s)
-{
-    if (nq == 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_queries_kernel, dim3(nq), dim3(256), 0, s, src, slot_query, nq, dim, qfloats, dst);
-    return hipGetLastError();
-}
-
 }  // namespace vsr
