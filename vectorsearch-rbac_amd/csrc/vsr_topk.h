@@ -201,12 +201,14 @@ __device__ __forceinline__ uint32_t wave_emit_selected(const uint64_t (&reg)[R],
 {
     const uint32_t want = n_real < k ? n_real : k;
     const bool full = n_real >= k && want > 0;
+    const uint32_t room = full ? want - 1 : want;            // never write past the list, whatever the keys are
     uint32_t at = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool sel = reg[r] != KEY_EMPTY && reg[r] <= tau && !(full && reg[r] == kth);
         const uint64_t m = __ballot(sel);
-        if (sel) dst[at + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = reg[r];
+        const uint32_t pos = at + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+        if (sel && pos < room) dst[pos] = reg[r];
         at += (uint32_t) __popcll(m);
     }
     if (full && lane == 0) dst[want - 1] = kth;
