@@ -19,16 +19,14 @@ import time
 import numpy as np
 
 from .engine import BITMAP, RANGES
+from .formats import read_shared_vectors, vector_from_text  # noqa: F401
 
 
 def parse_vector(v):
-    """Accepts pgvector's text form '[a,b,...]' (what the reference passes through SQL) or a sequence."""
-    if isinstance(v, str):
-        s = v.strip()
-        if not (s.startswith("[") and s.endswith("]")):
-            raise ValueError('invalid input syntax for type vector: "%s"' % v)      # vector.c:205-211
-        body = s[1:-1].strip()
-        return np.asarray([float(t) for t in body.split(",")] if body else [], dtype=np.float32)
+    """Accepts pgvector's text form '[a,b,...]' (what the reference passes through SQL; parsed with vector_in's grammar,
+    number parser and error texts, formats.vector_from_text) or a sequence of numbers."""
+    if isinstance(v, (str, bytes)):
+        return vector_from_text(v)
     return np.asarray(v, dtype=np.float32)
 
 
