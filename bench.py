@@ -111,7 +111,10 @@ def main():
     sim_world = int(os.environ.get("VSR_BENCH_SIM_WORLD", "0")) if world == 1 else 0
     parts = world if world > 1 else max(sim_world, 1)
     overlap = parts > 1 and not rehearsal
-    nbuf = 2 if overlap else 1
+    # Two batches in flight: consecutive batches alternate between two sessions (contexts = stream + workspaces) over
+    # the one resident corpus, so the selection / re-rank kernels of batch i run under the scan launch of batch i+1.
+    n_sess = 1 if rehearsal else max(1, min(2, int(os.environ.get("VSR_BENCH_SESSIONS", "2"))))
+    nbuf = 2 if (overlap or n_sess == 2) else 1
 
     def views(pack):
         return (pack[0:nk * 8].view(torch.int64).view(nq, k),            # raw u64 ordering keys
@@ -121,9 +124,16 @@ def main():
 
     d_packs = [torch.empty((rec,), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     d_views = [views(pk) for pk in d_packs]
-    d_keys, d_blk, d_doc, d_dist = d_views[0]
-    d_row = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    d_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    d_rows = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(nbuf)]
+    d_cnts = [torch.empty((nq,), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    s_main = torch.cuda.current_stream()
+    sessions, s_scan = [ctx], [s_main]
+    if n_sess == 2:
+        s2 = torch.cuda.Stream(device=dev)
+        ctx2 = vsrbac.Context(local_rank)
+        ctx2.set_stream(s2.cuda_stream)
+        sessions.append(ctx2)
+        s_scan.append(s2)
     if parts > 1:
         g_packs = [torch.full((parts * rec,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(nbuf)]   # [parts] records
         m_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -132,7 +142,6 @@ def main():
         m_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
         m_keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
     if overlap:
-        s_main = torch.cuda.current_stream()
         s_comm = torch.cuda.Stream(device=dev)
         mctx = vsrbac.Context(local_rank)                         # the merge runs on the exchange stream
         mctx.set_stream(s_comm.cuda_stream)
@@ -145,10 +154,11 @@ def main():
         step_no[0] += 1
         b = i % nbuf
         keys_b, blk_b, doc_b, dist_b = d_views[b]
+        sess, st = sessions[b % n_sess], s_scan[b % n_sess]
         if overlap and i >= 2:
-            s_main.wait_event(ev_sent[b])                         # batch i-2 has left record b
-        corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(blk_b), ptr(doc_b), ptr(d_row), ptr(dist_b),
-                             ptr(d_cnt), ptr(keys_b))
+            st.wait_event(ev_sent[b])                             # batch i-2 has left record b
+        corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(blk_b), ptr(doc_b), ptr(d_rows[b]), ptr(dist_b),
+                             ptr(d_cnts[b]), ptr(keys_b), session=sess)
         if world > 1 and rehearsal:
             torch.cuda.synchronize()
             hg = torch.empty((world * rec,), dtype=torch.uint8)
@@ -157,7 +167,7 @@ def main():
             ctx.merge_topk_packed_device(ptr(g_packs[0]), world, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist), ptr(m_keys),
                                          ptr(m_cnt))
         elif overlap:
-            ev_scan[b].record(s_main)
+            ev_scan[b].record(st)
             with torch.cuda.stream(s_comm):
                 s_comm.wait_event(ev_scan[b])
                 if world > 1:
@@ -177,17 +187,26 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.profiling(2)                                  # events around the main scan launch only (the roofline kernel)
-    ctx.stats_reset()
+    for sess in sessions:
+        sess.profiling(2)                             # events around the main scan launch only (the roofline kernel)
+        sess.stats_reset()
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
     t_enq = time.perf_counter() - t1                  # host time to enqueue the whole run (must stay below dt)
     barrier()
     dt = time.perf_counter() - t1
-    st = ctx.stats()
-    ctx.profiling(False)
-    flagged_total, _ = ctx.screening_check(0)         # K2 / seeding exactness flags over the whole run (expect 0)
+    st = None
+    flagged_total = 0
+    for sess in sessions:
+        one = sess.stats()
+        sess.profiling(False)
+        flagged_total += sess.screening_check(0)[0]   # K2 / seeding exactness flags over the whole run (expect 0)
+        if st is None:
+            st = one
+        else:
+            for key in ("scan_launches", "scan_ms", "scan_bytes", "scan_rows"):
+                st[key] = [a + b for a, b in zip(st[key], one[key])]
     if world > 1:
         ft = torch.tensor([flagged_total], dtype=torch.int64, device=dev if not rehearsal else "cpu")
         dist.all_reduce(ft, op=dist.ReduceOp.SUM)
@@ -196,6 +215,18 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if not rehearsal else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # ---- the same launch alone on the GPU: a few more batches, one in flight, same events (kernel quality, not value) ----
+    alone = None
+    if n_sess == 2:
+        ctx.profiling(2)
+        ctx.stats_reset()
+        for _ in range(5):
+            corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(d_views[0][1]), ptr(d_views[0][2]), ptr(d_rows[0]),
+                                 ptr(d_views[0][3]), ptr(d_cnts[0]), ptr(d_views[0][0]))
+        torch.cuda.synchronize()
+        alone = ctx.stats()
+        ctx.profiling(False)
 
     # ---- roofline of the dominant K1 kernel class (HIP events on the launch stream) ----
     cls = int(np.argmax(st["scan_ms"]))
@@ -213,6 +244,15 @@ def main():
         "all_scan_ms": [round(v, 3) for v in st["scan_ms"]], "all_scan_bytes": [int(v) for v in st["scan_bytes"]],
     }
 
+    if n_sess == 2:
+        roofline["note"] = ("two batches in flight: a launch's event-timed duration includes the time it shares the GPU "
+                            "with the other batch's kernels; `alone` is the same launch with one batch in flight")
+        if alone and alone["scan_launches"][cls]:
+            a_ms = alone["scan_ms"][cls] / alone["scan_launches"][cls]
+            a_by = alone["scan_bytes"][cls] / alone["scan_launches"][cls]
+            roofline["alone"] = {"launch_ms": round(a_ms, 4), "achieved": round(a_by / (a_ms * 1e-3) / 1e9, 1),
+                                 "frac": round(a_by / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "launches": int(alone["scan_launches"][cls])}
     workload_tag = f"{n}x{dim} k={k} q={nq} {args.mode} gpus={world}"
     try:      # HBM bytes per launch from a PMC pass of this same command (never measured inside the timed run)
         with open(args.traffic) as f:
@@ -243,6 +283,8 @@ def main():
         "screening_flagged_queries": int(flagged_total),
     }
 
+    d_keys, d_blk, d_doc, d_dist = d_views[0]         # slot 0 / session 0 from here on (everything above has drained)
+    d_row, d_cnt = d_rows[0], d_cnts[0]
     # ---- latency mode (informational, N = 1): the harness's call shape, one query per call ----
     if world == 1 and sim_world <= 1:
         m1 = min(200, nq)
@@ -286,11 +328,12 @@ def main():
                       f"cores (oracle built with pgvector's flags)",
         }
         out["parity_spot_check"] = {"queries": int(m), "ids_and_distances_identical": ok}
+    out["config"]["batches_in_flight"] = n_sess
     if parts > 1:
         out["config"]["exchange"] = ("all-gather + merge of batch i overlapped with the scan of batch i+1 (second stream)"
                                      if overlap else "serial (rehearsal through host memory)")
     if sim_world > 1:      # development check of the overlapped choreography on one GPU
-        last = d_views[(step_no[0] - 1) % nbuf]
+        last = d_views[(step_no[0] - 1) % nbuf]      # (the latency-mode loop below does not run in this mode)
         out["sim_world"] = {"parts": parts, "merged_equals_local": bool(torch.equal(m_keys, last[0]) and
                                                                         torch.equal(m_blk, last[1]) and
                                                                         torch.equal(m_dist, last[3]))}
@@ -316,6 +359,8 @@ def main():
     corpus.free()
     if overlap:
         mctx.close()
+    if n_sess == 2:
+        ctx2.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -134,6 +134,15 @@ int vsr_search_device(vsr_corpus* corpus, const float* d_queries, int nq, int di
                       int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows,
                       float* d_out_dist, int32_t* d_out_counts, uint64_t* d_out_keys);
 
+/* same, in the stream and workspaces of `session`: another context opened on the corpus's device (NULL = the corpus's
+ * own).  Two sessions let two batches over one corpus be in flight at once, so the small selection / re-rank kernels of
+ * one batch run under the scan launch of the other (a serving loop alternates sessions; bench.py does).  Flags and
+ * statistics (vsr_screening_check, vsr_stats_get) are per session. */
+int vsr_search_device_on(vsr_ctx* session, vsr_corpus* corpus, const float* d_queries, int nq, int dim, int k, int metric,
+                         const vsr_filter* const* filters,
+                         int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows,
+                         float* d_out_dist, int32_t* d_out_counts, uint64_t* d_out_keys);
+
 /* Shared passes of L2 / inner-product / cosine searches may run on the matrix cores: an fp32-MFMA screening keeps
  * 2k candidates per query and an exact re-rank reports the k best.  The re-rank flags a
  * query when the screening's rounding error could have excluded a true result; vsr_search re-runs flagged queries on

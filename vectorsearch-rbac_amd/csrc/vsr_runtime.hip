@@ -949,10 +949,9 @@ struct PassItem {
 // Queries -> passes.  A filter that is a union of permission classes (vsr_filter::parts) is scanned class by class, so
 // that every query whose role sees a class shares that class's pass: the corpus is then read at most
 // ceil(queries of the class / qmax) times per class instead of once per role partition.
-static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow_screening,
+static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, int metric, bool allow_screening,
                       const vsr_filter* const* filters, Plan& plan)
 {
-    const vsr_ctx* ctx = c->ctx;
     auto fof = [&](uint32_t q) { return filters ? filters[q] : nullptr; };
 
     // (filter part, query slot) items grouped by part: group ids in first-seen order, then a counting sort (stable, so
@@ -1200,11 +1199,12 @@ static void make_plan(const vsr_corpus* c, int nq, int k, int metric, bool allow
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Shared by the host and device entry points.  d_queries == nullptr: queries come from `h_queries`.
-static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_queries, int nq, int dim, int k, int metric,
-                       const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row, float* d_dist,
-                       int32_t* d_cnt, uint64_t* d_keys, bool allow_screening)
+// `ctx` is the session the search runs in (stream, workspaces, counters): the corpus's own context, or another context
+// of the same device (vsr_search_device_on) so that two batches over one corpus can be in flight at once.
+static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, const float* d_queries, int nq, int dim, int k,
+                       int metric, const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row,
+                       float* d_dist, int32_t* d_cnt, uint64_t* d_keys, bool allow_screening)
 {
-    vsr_ctx* ctx = c->ctx;
     const auto h0 = std::chrono::steady_clock::now();
     struct HostTimer {
         vsr_ctx* ctx;
@@ -1217,7 +1217,7 @@ static int search_impl(vsr_corpus* c, const float* h_queries, const float* d_que
     } host_timer{ctx, h0};
     static thread_local Plan plan;
     plan.reset();
-    make_plan(c, nq, k, metric, allow_screening, filters, plan);
+    make_plan(ctx, c, nq, k, metric, allow_screening, filters, plan);
     ctx->host_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
 
     const uint32_t kp = plan.keep;
@@ -1496,21 +1496,30 @@ static int check_search_args(const vsr_corpus* c, const void* queries, int nq, i
     return VSR_OK;
 }
 
+extern "C" int vsr_search_device_on(vsr_ctx* session, vsr_corpus* c, const float* d_queries, int nq, int dim, int k,
+                                    int metric, const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc,
+                                    int64_t* d_row, float* d_dist, int32_t* d_cnt, uint64_t* d_keys)
+{
+    int rc = check_search_args(c, d_queries, nq, dim, k, metric, filters, "vsr_search_device");
+    if (rc) return rc;
+    vsr_ctx* ctx = session ? session : c->ctx;
+    if (ctx->device != c->ctx->device) return fail(VSR_ERR_INVALID, "vsr_search_device_on: session and corpus are on different devices");
+    if (nq == 0) return VSR_OK;
+    if (!d_blk || !d_dist || !d_cnt) return fail(VSR_ERR_INVALID, "vsr_search_device: output is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!d_doc) {
+        if ((rc = ctx->d_misc.reserve((size_t) nq * k * sizeof(int32_t)))) return rc;
+        d_doc = ctx->d_misc.as<int32_t>();
+    }
+    return search_impl(ctx, c, nullptr, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys, true);
+}
+
 extern "C" int vsr_search_device(vsr_corpus* c, const float* d_queries, int nq, int dim, int k, int metric,
                                  const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row,
                                  float* d_dist, int32_t* d_cnt, uint64_t* d_keys)
 {
-    int rc = check_search_args(c, d_queries, nq, dim, k, metric, filters, "vsr_search_device");
-    if (rc) return rc;
-    if (nq == 0) return VSR_OK;
-    if (!d_blk || !d_dist || !d_cnt) return fail(VSR_ERR_INVALID, "vsr_search_device: output is NULL");
-    HIPCHK(hipSetDevice(c->ctx->device));
-    if (!d_doc) {
-        vsr_ctx* ctx = c->ctx;
-        if ((rc = ctx->d_misc.reserve((size_t) nq * k * sizeof(int32_t)))) return rc;
-        d_doc = ctx->d_misc.as<int32_t>();
-    }
-    return search_impl(c, nullptr, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys, true);
+    return vsr_search_device_on(nullptr, c, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt,
+                                d_keys);
 }
 
 extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, int k, int metric,
@@ -1531,7 +1540,7 @@ extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, 
     if ((rc = ctx->h_out.reserve(total))) return rc;
     char* d = ctx->d_out.as<char>();
     auto run = [&](const float* qs, int n, const vsr_filter* const* fs, bool screening) -> int {
-        int r = search_impl(c, qs, nullptr, n, dim, k, metric, fs, reinterpret_cast<int64_t*>(d + o_blk),
+        int r = search_impl(ctx, c, qs, nullptr, n, dim, k, metric, fs, reinterpret_cast<int64_t*>(d + o_blk),
                             reinterpret_cast<int32_t*>(d + o_doc), reinterpret_cast<int64_t*>(d + o_row),
                             reinterpret_cast<float*>(d + o_dist), reinterpret_cast<int32_t*>(d + o_cnt), nullptr, screening);
         if (r) return r;

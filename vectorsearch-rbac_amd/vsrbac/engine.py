@@ -253,9 +253,11 @@ class Corpus:
         return SearchResult(blk, doc, row, dist, cnt)
 
     def search_device(self, d_queries, nq, k, metric, filters, d_block, d_doc, d_rows, d_dist, d_counts, d_keys=None,
-                      dim=None):
-        """Device pointers (ints); enqueues on the context's stream, does not synchronise."""
+                      dim=None, session=None):
+        """Device pointers (ints); enqueues on the context's stream, does not synchronise.  `session`: another Context
+        of the same GPU whose stream and workspaces the search uses (two batches in flight over one corpus)."""
         farr, keep = self._filter_array(filters, nq)
-        check(self._lib.vsr_search_device(self._h, d_queries, nq, self.dim if dim is None else dim, int(k),
-                                          _metric(metric), farr, d_block, d_doc, d_rows, d_dist, d_counts, d_keys))
+        check(self._lib.vsr_search_device_on(session._h if session is not None else None, self._h, d_queries, nq,
+                                             self.dim if dim is None else dim, int(k), _metric(metric), farr, d_block,
+                                             d_doc, d_rows, d_dist, d_counts, d_keys))
         return keep
