@@ -113,8 +113,8 @@ def main():
     overlap = parts > 1 and not rehearsal
     # Two batches in flight: consecutive batches alternate between two sessions (contexts = stream + workspaces) over
     # the one resident corpus, so the selection / re-rank kernels of batch i run under the scan launch of batch i+1.
-    n_sess = 1 if rehearsal else max(1, min(2, int(os.environ.get("VSR_BENCH_SESSIONS", "2"))))
-    nbuf = 2 if (overlap or n_sess == 2) else 1
+    n_sess = 1 if rehearsal else max(1, min(4, int(os.environ.get("VSR_BENCH_SESSIONS", "2"))))
+    nbuf = max(2 if overlap else 1, n_sess)           # one result record (and gathered buffer) per batch in flight
 
     def views(pack):
         return (pack[0:nk * 8].view(torch.int64).view(nq, k),            # raw u64 ordering keys
@@ -128,12 +128,12 @@ def main():
     d_cnts = [torch.empty((nq,), dtype=torch.int32, device=dev) for _ in range(nbuf)]
     s_main = torch.cuda.current_stream()
     sessions, s_scan = [ctx], [s_main]
-    if n_sess == 2:
-        s2 = torch.cuda.Stream(device=dev)
-        ctx2 = vsrbac.Context(local_rank)
-        ctx2.set_stream(s2.cuda_stream)
-        sessions.append(ctx2)
-        s_scan.append(s2)
+    for _ in range(1, n_sess):
+        sx = torch.cuda.Stream(device=dev)
+        cx = vsrbac.Context(local_rank)
+        cx.set_stream(sx.cuda_stream)
+        sessions.append(cx)
+        s_scan.append(sx)
     if parts > 1:
         g_packs = [torch.full((parts * rec,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(nbuf)]   # [parts] records
         m_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -145,8 +145,8 @@ def main():
         s_comm = torch.cuda.Stream(device=dev)
         mctx = vsrbac.Context(local_rank)                         # the merge runs on the exchange stream
         mctx.set_stream(s_comm.cuda_stream)
-        ev_scan = [torch.cuda.Event() for _ in range(2)]          # record b holds the results of its batch
-        ev_sent = [torch.cuda.Event() for _ in range(2)]          # record b has been read by the exchange
+        ev_scan = [torch.cuda.Event() for _ in range(nbuf)]       # record b holds the results of its batch
+        ev_sent = [torch.cuda.Event() for _ in range(nbuf)]       # record b has been read by the exchange
     step_no = [0]
 
     def step():
@@ -155,8 +155,8 @@ def main():
         b = i % nbuf
         keys_b, blk_b, doc_b, dist_b = d_views[b]
         sess, st = sessions[b % n_sess], s_scan[b % n_sess]
-        if overlap and i >= 2:
-            st.wait_event(ev_sent[b])                             # batch i-2 has left record b
+        if overlap and i >= nbuf:
+            st.wait_event(ev_sent[b])                             # the batch that used record b before has left it
         corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(blk_b), ptr(doc_b), ptr(d_rows[b]), ptr(dist_b),
                              ptr(d_cnts[b]), ptr(keys_b), session=sess)
         if world > 1 and rehearsal:
@@ -218,7 +218,7 @@ def main():
 
     # ---- the same launch alone on the GPU: a few more batches, one in flight, same events (kernel quality, not value) ----
     alone = None
-    if n_sess == 2:
+    if n_sess > 1:
         ctx.profiling(2)
         ctx.stats_reset()
         for _ in range(5):
@@ -244,8 +244,9 @@ def main():
         "all_scan_ms": [round(v, 3) for v in st["scan_ms"]], "all_scan_bytes": [int(v) for v in st["scan_bytes"]],
     }
 
-    if n_sess == 2:
-        roofline["note"] = ("two batches in flight: a launch's event-timed duration includes the time it shares the GPU "
+    roofline["wall_rate"] = round(sum(st["scan_bytes"]) / dt / 1e9, 1)      # pass bytes per second of wall time, GB/s
+    if n_sess > 1:
+        roofline["note"] = (f"{n_sess} batches in flight: a launch's event-timed duration includes the time it shares the GPU "
                             "with the other batch's kernels; `alone` is the same launch with one batch in flight")
         if alone and alone["scan_launches"][cls]:
             a_ms = alone["scan_ms"][cls] / alone["scan_launches"][cls]
@@ -359,8 +360,8 @@ def main():
     corpus.free()
     if overlap:
         mctx.close()
-    if n_sess == 2:
-        ctx2.close()
+    for cx in sessions[1:]:
+        cx.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
