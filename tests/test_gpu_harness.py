@@ -149,3 +149,47 @@ def test_sharded_merge_equals_single_gpu(ctx, oracle, world, parts, shared):
         np.testing.assert_array_equal(o_dist[i, :m].cpu().numpy(), d.astype(np.float32))
     for c in shards:
         c.free()
+
+
+def test_two_sessions_in_flight_over_one_corpus(ctx, oracle, world):
+    """vsr_search_device_on: batches alternate between the corpus's own context and a second session (its own stream
+    and workspaces) without any synchronisation in between; every batch must equal the oracle, flags stay per session."""
+    import torch
+    import vsrbac
+    fx, x, blk, doc = world
+    n, k, nq, rounds = len(x), 25, 40, 6
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(29)
+    corpus = ctx.load_corpus(x, blk, doc)
+    corpus.load_rbac(fx["user_roles"], fx["permissions"])
+    other = vsrbac.Context(0)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    batches = []
+    for r in range(rounds):
+        users = rng.integers(1, fx["num_users"] + 1, nq)
+        q = x[rng.integers(0, n, nq)] + rng.integers(-2, 3, (nq, x.shape[1])).astype(np.float32)
+        d_q = torch.from_numpy(q).to(dev)
+        out = {"blk": torch.empty((nq, k), dtype=torch.int64, device=dev), "doc": torch.empty((nq, k), dtype=torch.int32, device=dev),
+               "row": torch.empty((nq, k), dtype=torch.int64, device=dev), "dist": torch.empty((nq, k), dtype=torch.float32, device=dev),
+               "cnt": torch.empty((nq,), dtype=torch.int32, device=dev)}
+        batches.append((users, q, d_q, out))
+    torch.cuda.synchronize()                                          # inputs are in place; the sessions use their own streams
+    for r, (users, q, d_q, out) in enumerate(batches):
+        filters = corpus.pack_filters([corpus.filter_for_user(int(u), vsrbac.RANGES if r % 3 else vsrbac.BITMAP) for u in users])
+        corpus.search_device(p(d_q), nq, k, "l2", filters, p(out["blk"]), p(out["doc"]), p(out["row"]), p(out["dist"]),
+                             p(out["cnt"]), None, session=other if r % 2 else None)
+    ctx.synchronize()
+    other.synchronize()
+    assert ctx.screening_check(0)[0] >= 0 and other.screening_check(0)[0] >= 0
+    for users, q, d_q, out in batches:
+        rows, dist, cnt = out["row"].cpu().numpy(), out["dist"].cpu().numpy(), out["cnt"].cpu().numpy()
+        for i in range(0, nq, 3):
+            mask = oracle.user_row_mask(int(users[i]), fx["user_roles"], fx["permissions"], doc)
+            idx, d = oracle.filtered_topk("l2", x, q[i], k, doc, blk, mask)
+            assert cnt[i] == idx.size
+            np.testing.assert_array_equal(rows[i, :idx.size], idx)
+            np.testing.assert_array_equal(dist[i, :idx.size], d.astype(np.float32))
+    with pytest.raises(vsrbac.VsrError):                              # NULL outputs are still rejected on a session
+        corpus.search_device(p(batches[0][2]), nq, k, "l2", None, None, None, None, None, None, None, session=other)
+    corpus.free()
+    other.close()
