@@ -26,7 +26,8 @@
  *   - host pointers are borrowed for the duration of the call; the library owns all device memory.
  *   - "_device" variants take device pointers and enqueue on the context's stream without synchronising.
  *   - a context is bound to one GPU and one host thread at a time; open one context per process after
- *     fork (PostgreSQL backends), never share across fork.
+ *     fork (PostgreSQL backends), never share across fork.  A corpus, its filters and every session searching it
+ *     (vsr_search_device_on) belong to ONE host thread at a time too: the planner keeps scratch marks in the filters.
  *   - there is no CPU fallback: without a usable gfx950 device vsr_open fails with VSR_ERR_NO_DEVICE.
  */
 #ifndef VSRBAC_H
