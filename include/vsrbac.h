@@ -138,7 +138,8 @@ int vsr_search_device(vsr_corpus* corpus, const float* d_queries, int nq, int di
 /* same, in the stream and workspaces of `session`: another context opened on the corpus's device (NULL = the corpus's
  * own).  Two sessions let two batches over one corpus be in flight at once, so the small selection / re-rank kernels of
  * one batch run under the scan launch of the other (a serving loop alternates sessions; bench.py does).  Flags and
- * statistics (vsr_screening_check, vsr_stats_get) are per session. */
+ * statistics (vsr_screening_check, vsr_stats_get) are per session.  vsr_corpus_free / vsr_filter_free wait for the
+ * corpus's own context only: vsr_synchronize every other session that searched the corpus before freeing it. */
 int vsr_search_device_on(vsr_ctx* session, vsr_corpus* corpus, const float* d_queries, int nq, int dim, int k, int metric,
                          const vsr_filter* const* filters,
                          int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows,
