@@ -149,10 +149,9 @@ hipError_t launch_mq(const ScanParams& p, int metric, uint32_t n_blocks, hipStre
 hipError_t launch_mfma(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
 inline size_t mfma_lds_bytes(uint32_t stride4, int nq = 16)
 {
-    const uint32_t nstage = (stride4 + 15) / 16;
+    (void) stride4;                                        // the queries never sit in LDS (registers, or streamed per stage)
     return (size_t) 4 * 64 * 16 * 16                       // 4 wave staging images (swizzled, no padding)
          + (size_t) 4 * 128 * 8                            // row index + |row|^2 per slot, double-buffered
-         + (nstage > 4 ? (size_t) 16 * nstage * 16 * 16 : 0)   // queries in LDS only when they do not fit registers
          + (size_t) nq * 20 + 32;
 }
 // K2 workgroups vote on compaction every K2_VOTE_EVERY tiles per wave (a workgroup barrier per tile costs more than
@@ -169,7 +168,7 @@ inline uint32_t mfma_cap_for_k(uint32_t kp)
     while (cap < 2 * kp + K2_SLACK) cap <<= 1;
     return cap;                    // sorted in the staging LDS: must stay <= 8192 keys (planner gate)
 }
-inline int mfma_qmax(uint32_t stride4) { return (stride4 + 15) / 16 <= 4 ? 32 : 16; }
+inline int mfma_qmax(uint32_t stride4) { (void) stride4; return 32; }
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 64 (one wave per query) | 256 | 1024

@@ -38,7 +38,8 @@ __device__ __forceinline__ float screen_value(float dot, float nx, float nq)
     else return 1.0f - dot * rsqrtf(nx * nq);
 }
 
-// NSTR > 0: B fragments of NSTR stages live in registers (d <= 64 * NSTR); NSTR == 0: B read from LDS per use.
+// NSTR > 0: B fragments of NSTR stages live in registers (d <= 64 * NSTR); NSTR == 0: the B fragments of one stage at a
+// time are streamed from global memory (L1 / L2 resident: 3 KB per query at d = 768) one stage ahead of their use.
 // SAMPLE only gives the seeding pass (p.sample_stride > 1) its own kernel symbol in profiles.
 // NG: 16-query groups served by one pass (1 or 2): the staged tile is multiplied against NG sets of B fragments.
 template <int METRIC, int NSTR, bool SAMPLE, int NG>
@@ -69,7 +70,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
 
     const uint32_t stride4 = p.stride4, cap = p.cap, keep = p.k;
     const uint32_t nstage = (stride4 + MF_S - 1) / MF_S;
-    const uint32_t qpitch = nstage * MF_S;
     const uint32_t q_count = grp.q_count;
 
     float4*   stage = reinterpret_cast<float4*>(smem) + (size_t) wave * 64 * MF_S;
@@ -77,9 +77,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     int32_t*  rowidx = reinterpret_cast<int32_t*>(after) + wave * 128;             // [wave][2][64]
     float*    rownorm = reinterpret_cast<float*>(after + MF_WAVES * 128 * 4) + wave * 128;
     constexpr int NQ = MF_NQ * NG;
-    static_assert(NSTR > 0 || NG == 1, "LDS-resident queries: one group only");
-    float4*   qlds = reinterpret_cast<float4*>(after + MF_WAVES * 128 * 8);      // NSTR == 0 only
-    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(qlds + (NSTR == 0 ? (size_t) MF_NQ * qpitch : 0));
+    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(after + MF_WAVES * 128 * 8);
     float*    qnl = reinterpret_cast<float*>(ctrl + NQ);
     uint32_t* flags = reinterpret_cast<uint32_t*>(qnl + NQ);
     uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem);
@@ -93,14 +91,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
             atomicAdd(&p.dbg[p.tau_init[slot] == KEY_EMPTY ? 3 : 4], 1ull);
     }
     if (tid < 4) flags[tid] = 0;
-    if constexpr (NSTR == 0) {
-        for (uint32_t qi = 0; qi < (uint32_t) MF_NQ; ++qi) {                   // pad columns repeat query 0
-            const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
-            const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
-            for (uint32_t i = tid; i < qpitch; i += MF_THREADS)
-                qlds[(size_t) qi * qpitch + i] = i < stride4 ? qsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
     __syncthreads();
 
     // MFMA lane roles: A operand lane = (row i, k-quad kq); B operand / result lane = (k-quad kq, query jq)
@@ -110,13 +100,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     constexpr int NB = NSTR > 0 ? NSTR : 1;
     float4 bq[NG][NB][4];
     float my_qn[NG];
+    const float4* qsrc_g[NG];                                                  // this lane's query column per group
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const uint32_t qi = (uint32_t) (g * MF_NQ + jq);
         my_qn[g] = qnl[qi];
+        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];   // pad columns repeat query 0
+        const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
+        qsrc_g[g] = qsrc;
         if constexpr (NSTR > 0) {                                              // B fragments straight from global
-            const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
-            const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
 #pragma unroll
             for (int s = 0; s < NSTR; ++s)
 #pragma unroll
@@ -126,6 +118,27 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                 }
         }
     }
+    // NSTR == 0: B fragments of the stage in use (bcur) and of the next one (bnxt, raw loads: zeroed for chunks past
+    // the row end only when they become bcur, so that nothing touches them while they are in flight)
+    f32x4 bcur[NG][4], bnxt[NG][4];
+    auto issue_b = [&](uint32_t s_) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t idx = s_ * MF_S + (uint32_t) (4 * t + kq);
+                bnxt[g][t] = *reinterpret_cast<const f32x4*>(qsrc_g[g] + (idx < stride4 ? idx : 0u));
+            }
+    };
+    auto take_b = [&](uint32_t s_) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = s_ * MF_S + (uint32_t) (4 * t + kq) < stride4;
+                bcur[g][t] = ok ? bnxt[g][t] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    };
 
     const uint32_t rw = p.rw, tps = 64 / rw;
     const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
@@ -258,6 +271,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) acc[g][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+            if constexpr (NSTR == 0) {
+                issue_b(0);
+                take_b(0);
+            }
             for (uint32_t s = 0; s < nstage; ++s) {
 #pragma unroll
                 for (int u = 0; u < MF_S; ++u) {
@@ -266,6 +283,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                 }
                 if (s + 1 < nstage) issue(s + 1, ridx);                        // in flight during the MFMAs
                 else prepare_next();                                           // next tile's first loads too
+                if constexpr (NSTR == 0)
+                    if (s + 1 < nstage) issue_b(s + 1);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     float4 b[NG];
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                             for (int s2 = 1; s2 < NSTR; ++s2)
                                 if (s == (uint32_t) s2) b[g] = bq[g][s2][t];
                         } else {
-                            b[g] = qlds[(size_t) jq * qpitch + s * MF_S + 4 * t + kq];
+                            b[g] = make_float4(bcur[g][t][0], bcur[g][t][1], bcur[g][t][2], bcur[g][t][3]);
                         }
                     }
                     // A fragments of the four 16-row sub-tiles first, then the MFMAs component by component so that
@@ -307,6 +326,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                         for (int g = 0; g < NG; ++g)
                             acc[g][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sub].w, b[g].w, acc[g][sub], 0, 0, 0);
                 }
+                if constexpr (NSTR == 0)
+                    if (s + 1 < nstage) take_b(s + 1);                         // landed under this stage's MFMAs
             }
 
             // results: acc[g][sub][r] = dot(row sub*16 + kq*4 + r, query g*16 + jq).  Every lane screens its 16 pairs per
@@ -459,7 +480,7 @@ hipError_t launch_mfma_metric(const ScanParams& p, uint32_t n_blocks, hipStream_
     };
     const bool sample = p.sample_stride > 1;
     if (nstage > 4) {
-        if (ng != 1) return hipErrorInvalidValue;
+        if (ng == 2) return sample ? launch(mfma_scan_kernel<METRIC, 0, true, 2>) : launch(mfma_scan_kernel<METRIC, 0, false, 2>);
         return sample ? launch(mfma_scan_kernel<METRIC, 0, true, 1>) : launch(mfma_scan_kernel<METRIC, 0, false, 1>);
     }
     if (nstage <= 2) {

@@ -138,14 +138,15 @@ struct vsr_ctx {
     // knobs
     int block_budget = 0;          // 0 = 4 * CUs
     int min_rows_per_block = 256;
-    int max_qb = 16;               // queries per shared pass; 32 (two MFMA query groups) is built and tested but does
-                                   // not raise throughput on MI355X (measured), it only shrinks the algorithmic bytes
+    int max_qb = 16;               // queries per shared pass.  32 (two MFMA query groups) does not pay at d = 128; the planner
+                                   // picks it by itself for long rows when the query groups fill it (make_plan)
     uint32_t debug = 0;            // VSR_DEBUG bits (measurement only)
     double extra_ms[2] = {0, 0};   // sample scan, seed select (profiling only)
     double host_us[3] = {0, 0, 0}; // VSR_DEBUG: host time in make_plan / waiting for the staging buffer / whole search_impl
     long   host_calls = 0;
     unsigned long long* d_dbg = nullptr;
     bool no_classes = false;       // VSR_NO_CLASSES=1: scan role partitions whole (A/B measurements)
+    bool max_qb_set = false;       // VSR_MAX_QB / vsr_tune chose the queries per pass: the planner does not override it
     bool no_xcd_map = false;       // VSR_NO_XCD_MAP=1: workgroups in pass order instead of XCD-aware bundles (A/B)
     bool no_mq = false;            // VSR_NO_MQ=1: keep shared passes on K1 (A/B measurements)
 };
@@ -248,7 +249,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     const char* env;
     if ((env = getenv("VSR_BLOCK_BUDGET"))) ctx->block_budget = atoi(env);
     if ((env = getenv("VSR_MIN_ROWS_PER_BLOCK"))) ctx->min_rows_per_block = std::max(1, atoi(env));
-    if ((env = getenv("VSR_MAX_QB"))) ctx->max_qb = std::max(1, atoi(env));
+    if ((env = getenv("VSR_MAX_QB"))) { ctx->max_qb = std::max(1, atoi(env)); ctx->max_qb_set = true; }
     if ((env = getenv("VSR_NO_MQ"))) ctx->no_mq = atoi(env) != 0;
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
@@ -316,7 +317,7 @@ extern "C" int vsr_tune(vsr_ctx* ctx, int block_budget, int min_rows_per_block, 
     if (!ctx) return fail(VSR_ERR_INVALID, "vsr_tune: ctx is NULL");
     if (block_budget >= 0) ctx->block_budget = block_budget;
     if (min_rows_per_block > 0) ctx->min_rows_per_block = min_rows_per_block;
-    if (max_qb > 0) ctx->max_qb = max_qb;
+    if (max_qb > 0) { ctx->max_qb = max_qb; ctx->max_qb_set = true; }
     return VSR_OK;
 }
 
@@ -1010,6 +1011,18 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     const bool k2_ok = allow_screening && ctx->screening && c->k2_safe && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
                        mfma_cap_for_k(keep) <= 8192 && ctx->max_qb >= 16 && mfma_lds_bytes(c->stride4) <= 150 * 1024;
     int qmax = k2_ok ? std::min(ctx->max_qb, mfma_qmax(c->stride4)) : std::min(ctx->max_qb, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
+    if (k2_ok && !ctx->max_qb_set && qmax >= 16 && c->stride4 > 64) {
+        // long rows (d > 256): a pass costs mostly its row bytes, so two 16-query MFMA groups per pass (half the passes)
+        // pay off -- but only when the query groups fill them (an unfiltered 1000-query batch: 17 % less time at
+        // d = 768; role partitions with ~25 queries per class: 2.7x more, the second group would be mostly padding)
+        uint64_t used = 0, slots = 0;
+        for (size_t g = 0; g < gcount.size(); ++g) {
+            const uint32_t cnt = gcount[g] - (g ? gcount[g - 1] : 0u);    // gcount holds end offsets after the scatter
+            used += cnt;
+            slots += (uint64_t) (cnt + 31) / 32 * 32;
+        }
+        if (slots && used * 10 >= slots * 9) qmax = std::min(32, mfma_qmax(c->stride4));
+    }
     qmax = qmax >= 4 ? qmax / 4 * 4 : 1;
 
     struct Pass { const vsr_filter* f; uint32_t q_off, q_count; int64_t rows; uint32_t n_tiles; };
