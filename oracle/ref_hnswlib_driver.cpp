@@ -78,4 +78,41 @@ int ref_hnsw_topk(int metric, int dim, const float* rows, int64_t n, int M, int 
     }
 }
 
+// A persistent HNSW index for the reported CPU baseline (tools/cpu_hnsw_baseline.py): build once, query with several ef.
+struct RefHnsw {
+    std::unique_ptr<hnswlib::SpaceInterface<float>> space;
+    std::unique_ptr<hnswlib::HierarchicalNSW<float>> index;
+    int dim;
+};
+
+void* ref_hnsw_open(int metric, int dim, const float* rows, int64_t n, int M, int ef_construction)
+{
+    try {
+        auto* h = new RefHnsw();
+        h->dim = dim;
+        h->space = make_space(metric, dim);
+        h->index = std::make_unique<hnswlib::HierarchicalNSW<float>>(h->space.get(), (size_t) n, (size_t) M,
+                                                                     (size_t) ef_construction, 100);
+        for (int64_t i = 0; i < n; ++i) h->index->addPoint(rows + (size_t) i * dim, (hnswlib::labeltype) i);
+        return h;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+int ref_hnsw_query(void* handle, int ef_search, const float* queries, int nq, int k, int64_t* out_ids, float* out_dist,
+                   int32_t* out_counts)
+{
+    auto* h = static_cast<RefHnsw*>(handle);
+    if (!h) return 1;
+    try {
+        h->index->setEf((size_t) ef_search);
+        return run_queries(*h->index, queries, nq, h->dim, k, nullptr, out_ids, out_dist, out_counts);
+    } catch (...) {
+        return 2;
+    }
+}
+
+void ref_hnsw_close(void* handle) { delete static_cast<RefHnsw*>(handle); }
+
 }  // extern "C"
