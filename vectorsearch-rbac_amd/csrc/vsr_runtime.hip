@@ -138,6 +138,7 @@ struct vsr_ctx {
     // knobs
     int block_budget = 0;          // 0 = 4 * CUs
     int min_rows_per_block = 256;
+    int min_shared_rows = 2048;    // rows per workgroup of a shared pass (VSR_MIN_SHARED_ROWS)
     int max_qb = 16;               // queries per shared pass.  32 (two MFMA query groups) does not pay at d = 128; the planner
                                    // picks it by itself for long rows when the query groups fill it (make_plan)
     uint32_t debug = 0;            // VSR_DEBUG bits (measurement only)
@@ -255,6 +256,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
     if ((env = getenv("VSR_NO_XCD_MAP"))) ctx->no_xcd_map = atoi(env) != 0;
+    if ((env = getenv("VSR_MIN_SHARED_ROWS"))) ctx->min_shared_rows = std::max(64, atoi(env));
     if ((env = getenv("VSR_SEED_MIN_PASS"))) ctx->seed_min_pass_rows = atoll(env);
     if ((env = getenv("VSR_SEED_STRIDE"))) SEED_STRIDE = (uint32_t) std::max(2, atoi(env));
     if ((env = getenv("VSR_SEED_DIV"))) SEED_BLOCK_DIV = (uint32_t) std::max(1, atoi(env));
@@ -1078,7 +1080,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     for (auto& p : passes) {
         if (p.n_tiles == 0 || p.rows == 0) continue;       // empty filter part: nothing to scan
         int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows - 1) / total_rows;
-        const int64_t min_rows = p.q_count > 1 ? std::max<int64_t>(ctx->min_rows_per_block, 2048) : ctx->min_rows_per_block;
+        const int64_t min_rows = p.q_count > 1 ? std::max<int64_t>(ctx->min_rows_per_block, ctx->min_shared_rows) : ctx->min_rows_per_block;
         nb = std::min<int64_t>(nb, std::max<int64_t>(1, p.rows / min_rows));   // shared passes need rows to prune on
         nb = std::min<int64_t>(nb, std::max<uint32_t>(1, p.n_tiles));
         nb = std::max<int64_t>(nb, 1);
