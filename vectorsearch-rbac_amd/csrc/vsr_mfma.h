@@ -12,8 +12,9 @@
 //
 // Data path per wave and 64-row tile: coalesced global loads (256-byte row segments) -> wave-private LDS image,
 // XOR-swizzled so that the A-fragment reads (lane = (row i, k-quad kq) reads float4 [i][4t+kq]) are conflict-free
-// -> 4 x 16-row sub-tiles x 4 k-steps of MFMA per float4.  The 16 query vectors sit in registers as B fragments
-// for the whole kernel when d <= 256 (32 VGPRs at d = 128), else they are re-read from LDS.
+// -> 4 x 16-row sub-tiles x 4 k-steps of MFMA per float4.  The 16 (or 2 x 16) query vectors sit in registers as B
+// fragments for the whole kernel when d <= 256 (32 VGPRs at d = 128); for longer rows the fragments of one 64-float
+// stage at a time are streamed from global memory (L1 / L2 resident) one stage ahead of their use.
 #pragma once
 #include <type_traits>
 #include "vsr_device.h"
