@@ -494,3 +494,55 @@ def test_config2_sift1m_role_prefilter(ctx, oracle):
             recomputed = np.sqrt(((x[res.rows[i]].astype(np.float64) - x[qrows[i]].astype(np.float64)) ** 2).sum(1))
             np.testing.assert_array_equal(d, recomputed.astype(np.float32))
     corpus.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# randomized differential test: many small shapes through every planner branch, exact against the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_shapes_exact(ctx, oracle, seed):
+    """Integer-valued rows small enough that fp32 sums are exact for every metric and dimension drawn (31^2 * 768 < 2^24),
+    so ids and values must equal the oracle bit for bit whatever kernels the planner picks: single-query K1, shared
+    passes on K2 (one or two query groups, registers or streamed B fragments) or K1m (L1), bitmaps or ranges or class
+    decomposition, one or two selection levels, seeded or not."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(4):
+        n = int(rng.choice([60, 700, 5000, 30000]))
+        dim = int(rng.choice([4, 16, 64, 100, 128, 200, 320, 768]))
+        k = int(rng.choice([1, 5, 10, 64, 100, 200]))
+        nq = int(rng.choice([1, 2, 7, 16, 33, 100]))
+        metric = str(rng.choice(["l2", "ip", "l1"]))
+        x = np.clip(np.rint(np.abs(rng.normal(0, 6, (n, dim)))), 0, 31).astype(np.float32)
+        rows_per_doc = int(rng.choice([1, 7, 50]))
+        blk, doc = _ids(n, rows_per_doc)
+        corpus = ctx.load_corpus(x, blk, doc)
+        q = np.clip(np.rint(np.abs(rng.normal(0, 6, (nq, dim)))), 0, 31).astype(np.float32)
+        kind = str(rng.choice(["none", "mask", "rbac"]))
+        masks = [None] * nq
+        filters = None
+        if kind == "mask":
+            base = [(rng.random(n) < p).astype(np.uint8) for p in (0.03, 0.5)]
+            fs = [corpus.filter_from_bytemask(m) for m in base]
+            pick = rng.integers(0, 2, nq)
+            filters = [fs[j] for j in pick]
+            masks = [base[j] for j in pick]
+        elif kind == "rbac":
+            ndocs = int(doc.max())
+            nroles, nusers = 5, 9
+            perms = sorted({(int(r), int(d)) for r in range(1, nroles + 1)
+                            for d in rng.choice(np.arange(1, ndocs + 1), size=max(1, ndocs // 3), replace=False)})
+            ur = sorted({(u, int(r)) for u in range(1, nusers + 1) for r in rng.choice(np.arange(1, nroles + 1), size=int(rng.integers(1, 3)), replace=False)})
+            corpus.load_rbac(ur, perms)
+            users = rng.integers(1, nusers + 1, nq)
+            mode = vsrbac_mode(rng)
+            filters = [corpus.filter_for_user(int(u), mode) for u in users]
+            masks = [oracle.user_row_mask(int(u), ur, perms, doc) for u in users]
+        res = corpus.search(q, k, metric, filters)
+        for i in range(0, nq, max(1, nq // 6)):
+            _expect_exact(oracle, res, i, metric, x, q[i], k, doc, blk, masks[i])
+        corpus.free()
+
+
+def vsrbac_mode(rng):
+    import vsrbac
+    return vsrbac.RANGES if rng.random() < 0.5 else vsrbac.BITMAP
