@@ -308,7 +308,9 @@ extern "C" int vsr_synchronize(vsr_ctx* ctx)
 extern "C" int vsr_device_info(vsr_ctx* ctx, char* name, int name_len, int* cus, int64_t* hbm)
 {
     if (!ctx) return fail(VSR_ERR_INVALID, "vsr_device_info: ctx is NULL");
-    if (name && name_len > 0) snprintf(name, (size_t) name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (name && name_len > 0)      // some boxes report an empty marketing name: say what the architecture implies
+        snprintf(name, (size_t) name_len, "%s (%s)", ctx->prop.name[0] ? ctx->prop.name : "AMD Instinct (CDNA4)",
+                 ctx->prop.gcnArchName);
     if (cus) *cus = ctx->prop.multiProcessorCount;
     if (hbm) *hbm = (int64_t) ctx->prop.totalGlobalMem;
     return VSR_OK;
