@@ -109,3 +109,17 @@ def test_run_search_experiment_protocol():
     assert len(calls) == 9
     assert out["avg_recall"] == 0.5 and abs(out["avg_query_time"] - 0.004) < 1e-12 and abs(out["qps"] - 250) < 1e-6
     assert set(out["all_results"][0]) == {"user_id", "query_vector", "recall", "query_time", "qps"}
+
+
+def test_planner_output_to_tables():
+    """The planner's in-memory dicts (sets, frozenset / tuple combinations, {partition: roles} trackers) become the two
+    tables Deployment.load_partitions takes; unknown partitions are an error, not a silent hole in the result."""
+    from vsrbac.harness import planner_output_to_tables
+    pa = {0: {5, 1, 3}, 7: {2}, 9: set()}
+    trackers = {frozenset({2, 1}): {0: {1, 2}, 7: {2}}, (3,): {9: {3}}, 4: {0: {4}}}
+    docs, combs = planner_output_to_tables(pa, trackers)
+    assert docs == {0: [1, 3, 5], 7: [2], 9: []}
+    assert combs == {(1, 2): [0, 7], (3,): [9], (4,): [0]}
+    import pytest
+    with pytest.raises(ValueError, match="unknown partitions"):
+        planner_output_to_tables(pa, {(1,): {42: {1}}})

@@ -30,6 +30,21 @@ def parse_vector(v):
     return np.asarray(v, dtype=np.float32)
 
 
+def planner_output_to_tables(partition_assignment, comb_role_trackers):
+    """(partition_docs, comb_role_partitions) in the shape `Deployment.load_partitions` takes, from the planner's dicts:
+    documents per partition sorted, one (combination -> partition ids) row set like the CombRolePartitions table."""
+    partition_docs = {int(p): sorted(int(d) for d in docs) for p, docs in partition_assignment.items()}
+    combs = {}
+    for comb, parts in comb_role_trackers.items():
+        key = tuple(sorted(int(r) for r in (comb if isinstance(comb, (tuple, list, set, frozenset)) else (comb,))))
+        pids = sorted(int(p) for p in (parts.keys() if hasattr(parts, "keys") else parts))
+        missing = [p for p in pids if p not in partition_docs]
+        if missing:
+            raise ValueError(f"combination {key} refers to unknown partitions {missing}")
+        combs[key] = pids
+    return partition_docs, combs
+
+
 def load_query_dataset(path):
     """query_dataset.json: list of {user_id, query_vector, topk, query_block_selectivity}
     (services/read_dataset_function.py:705-710,1049-1062)."""
@@ -128,6 +143,13 @@ class Deployment:
         return self._rows(res), secs
 
     # ---- dynamic partitions ---------------------------------------------------------------------
+    def load_planner_output(self, partition_assignment, comb_role_trackers):
+        """The in-memory result of the reference's partition planner, as its loader receives it
+        (initialize_partitions_and_role_mappings, load_result_to_database.py:286-299): `partition_assignment`
+        {partition_id: set(document_id)} and `comb_role_trackers` {role combination: {partition_id: set(roles)}}
+        (AnonySys_dynamic_partition.py:312-320)."""
+        self.load_partitions(*planner_output_to_tables(partition_assignment, comb_role_trackers))
+
     def load_partitions(self, partition_docs, comb_role_partitions):
         """partition_docs: {partition_id: [document_id,...]} (load_result_to_database.py:207-240);
         comb_role_partitions: {(role,...): [partition_id,...]} (CombRolePartitions, :293-299)."""
