@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py — QPS of RBAC-filtered exact k-NN on MI355X (BASELINE.json's metric), with the K1 roofline
-and a CPU baseline timed beside it.
+"""bench.py — QPS of RBAC-filtered exact k-NN on MI355X (BASELINE.json's metric), with the roofline of the dominant
+scan kernel and a CPU baseline timed beside it.
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W]          (N > 1: spawns its own ranks through torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): synthetic SIFT10M-like corpus (10M x 128 fp32, integer-valued, 100 rows per
-document), tree RBAC (1000 users / 100 roles), k = 100, L2, role-level filter applied as a
-pre-filter (only the rows of the user's role partition are scanned).  A step = one batch of `--queries`
-queries (uniform rows x uniform users) through the whole hot path: K1 scan (distance + permission + running
-top-k) and K5 select; with N > 1 the corpus is sharded by contiguous row range (strong scaling, total work
-fixed), every rank searches its shard and the per-rank top-k lists are all-gathered over RCCL and merged.
-Inputs (corpus, filters, queries) are resident in HBM when the timed region starts.
+Workload (config.workload): synthetic SIFT10M-like corpus (10M x 128 fp32, integer-valued, 100 rows per document),
+tree RBAC (1000 users / 100 roles), k = 100, L2.  A step = one batch of `--queries` queries (uniform rows x
+uniform users, a fresh batch per step from the seeded stream) through the whole hot path: staging, threshold sample,
+shared-pass scan on the matrix cores (distance + permission + running top-k), selection, exact re-rank.  Two legs are
+timed with the same K steps each:
 
-No part of the timed path touches the CPU oracle; it is used only by the cpu_baseline leg (rank 0, N = 1)
-and for a parity spot-check of the GPU results on the same sample.
+  value / roofline      role-level filter applied as a PRE-filter: only the rows of the user's role partition are
+                        scanned (BASELINE config 2's mode on the metric's SIFT10M corpus)
+  postfilter{...}       the same users as row-level-security bitmaps tested in the distance loop (BASELINE config 4's
+                        mode: RLS post-filter), whole-corpus scan order
+
+With N > 1 the corpus is sharded by contiguous row range (strong scaling: total work fixed), every rank searches its
+shard and the per-rank top-k lists are all-gathered over RCCL and merged on the GPU.  Inputs (corpus, filters,
+queries) are resident in HBM when the timed region starts.
+
+roofline: the physical floor of the main scan launch is max(unique row bytes / 8 TB/s, 2 * d * (row, query) pairs /
+157.3 TFLOP/s of fp32 MFMA); `frac` = that floor / the launch's HIP-event duration, `bound` names the larger term.
+The pass-structure figure of round 1 (bytes of every pass, re-reads from L2 included) is kept as `pass_bytes_rate`.
+
+No part of the timed path touches the CPU oracle; it is used only by the cpu_baseline leg (rank 0, N = 1) and for the
+parity spot-check of the GPU results on the same sample.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +44,7 @@ for p in (ROOT, os.path.join(ROOT, "vectorsearch-rbac_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290
+MFMA_F32_PEAK_TF = 157.3       # fp32 matrix peak (v_mfma_f32_16x16x4_f32), same guide
 
 
 def parse():
@@ -42,10 +56,12 @@ def parse():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--queries", type=int, default=1000, help="queries per step")
-    ap.add_argument("--mode", choices=["prefilter", "postfilter"], default="prefilter")
+    ap.add_argument("--legs", default="prefilter,postfilter", help="timed legs (the first one is the headline)")
+    ap.add_argument("--batches", type=int, default=16, help="distinct query batches cycled through the steps")
+    ap.add_argument("--sustained-s", type=float, default=2.0, help="extra untimed-by-the-driver leg: seconds of steps")
     ap.add_argument("--cpu-queries", type=int, default=1000, help="sample size of the CPU baseline leg")
     ap.add_argument("--cpu-reps", type=int, default=2, help="repetitions of the CPU sample (10-30 s of CPU work)")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r1", "traffic.json"),
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r2", "traffic.json"),
                     help="PMC-derived HBM bytes per launch (tools/pmc_traffic.py) for roofline.traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20251121)
@@ -56,8 +72,59 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def self_launch(args):
+    """--gpus N > 1 without a rank environment: spawn the N ranks as a CHILD (never re-exec a process that may touch
+    the GPU), relay rank 0's JSON line through the inherited stdout, exit with the child's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+def roofline_of(st, dim, kernel, n_sess, alone=None):
+    """Honest floors of the dominant scan launch class from the library's statistics (HIP events on the launch stream)."""
+    cls = int(np.argmax(st["scan_ms"]))
+    launches = max(1, st["scan_launches"][cls])
+    ms = st["scan_ms"][cls] / launches
+    pass_bytes = st["scan_bytes"][cls] / launches
+    pairs = st["scan_pairs"][cls] / launches
+    unique_bytes = st["unique_rows"][cls] / launches * dim * 4
+    flops = 2.0 * dim * pairs
+    t_hbm, t_mfma = unique_bytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
+    sec = ms * 1e-3
+
+    def floors(seconds):
+        if t_hbm >= t_mfma:
+            return "hbm", unique_bytes / seconds / 1e9, HBM_PEAK_GBS, "GB/s"
+        return "mfma", flops / seconds / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+
+    bound, achieved, peak, unit = floors(sec) if sec > 0 else ("hbm", 0.0, HBM_PEAK_GBS, "GB/s")
+    r = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+         "traffic": None, "kernel": kernel, "launch_ms": round(ms, 4), "launches": int(launches),
+         "unique_bytes": int(unique_bytes), "flops": int(flops),
+         "floor_ms": {"hbm_8TBs": round(t_hbm * 1e3, 4), "mfma_f32_157TF": round(t_mfma * 1e3, 4)},
+         "hbm_frac_unique_bytes": round(unique_bytes / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
+         "mfma_frac": round(flops / sec / 1e12 / MFMA_F32_PEAK_TF, 4) if sec > 0 else 0.0,
+         "pass_bytes_per_launch": int(pass_bytes),
+         "pass_bytes_rate": round(pass_bytes / sec / 1e9, 1) if sec > 0 else 0.0,
+         "all_scan_ms": [round(v, 3) for v in st["scan_ms"]]}
+    if n_sess > 1:
+        r["note"] = (f"{n_sess} batches in flight: a launch's event-timed duration includes the time it shares the GPU "
+                     "with the other batch's kernels; `alone` is the same launch with one batch in flight")
+    if alone and alone["scan_launches"][cls]:
+        a_ms = alone["scan_ms"][cls] / alone["scan_launches"][cls]
+        _, a_ach, a_peak, _ = floors(a_ms * 1e-3)
+        r["alone"] = {"launch_ms": round(a_ms, 4), "achieved": round(a_ach, 2), "frac": round(a_ach / a_peak, 4),
+                      "launches": int(alone["scan_launches"][cls])}
+    return r
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
     import vsrbac
@@ -68,7 +135,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     # rehearsal on a 1-GPU box only: VSR_BENCH_REHEARSAL=1 puts every rank on GPU 0 and exchanges through gloo
@@ -85,23 +152,30 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     n, dim, k, nq = args.rows, args.dim, args.k, args.queries
+    legs = [m for m in args.legs.split(",") if m]
     lo, hi = shard_bounds(n, world, rank, align=100)  # keep documents (100 rows) whole per shard
     t0 = time.time()
     x, blk, doc = sift_like_corpus(hi - lo, dim, seed=args.seed, start=lo)
     rbac = tree_rbac(num_users=1000, num_roles=100, num_docs=n // 100, seed=args.seed)
-    qrow, quser = sample_queries(nq, n, 1000, seed=args.seed)
-    qvec = sift_like_rows_at(qrow, dim, args.seed)    # query vectors = corpus rows (read_dataset_function.py:736-737)
+    nb = max(1, min(args.batches, args.steps + args.warmup))
+    batches = []                                      # fresh (rows, users) per step from the seeded stream, cycled
+    for b in range(nb):
+        qrow, quser = sample_queries(nq, n, 1000, seed=args.seed + 1000 * b)
+        batches.append((qrow, quser))
+    allrows = np.concatenate([qr for qr, _ in batches])
+    allvec = sift_like_rows_at(allrows, dim, args.seed)   # query vectors = corpus rows (read_dataset_function.py:736-737)
     t_gen = time.time() - t0
 
     ctx = vsrbac.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     corpus = ctx.load_corpus(x, blk, doc, row_offset=lo)
     corpus.load_rbac(rbac.user_roles, rbac.permissions)
-    mode = vsrbac.RANGES if args.mode == "prefilter" else vsrbac.BITMAP
-    filters = corpus.pack_filters([corpus.filter_for_user(int(u), mode) for u in quser])
+    MODES = {"prefilter": vsrbac.RANGES, "postfilter": vsrbac.BITMAP}
+    d_qs = [torch.from_numpy(allvec[b * nq:(b + 1) * nq]).to(dev) for b in range(nb)]
+    filt = {m: [corpus.pack_filters([corpus.filter_for_user(int(u), MODES[m]) for u in quser]) for _, quser in batches]
+            for m in legs}
     t_load = time.time() - t0 - t_gen
 
-    d_q = torch.from_numpy(qvec).to(dev)
     # one packed result record per rank {keys u64, block i64, doc i32, dist f32}[nq][k]: a single all-gather moves it
     rec = ctx.packed_result_bytes(nq, k)
     nk = nq * k
@@ -147,20 +221,20 @@ def main():
         mctx.set_stream(s_comm.cuda_stream)
         ev_scan = [torch.cuda.Event() for _ in range(nbuf)]       # record b holds the results of its batch
         ev_sent = [torch.cuda.Event() for _ in range(nbuf)]       # record b has been read by the exchange
-    step_no = [0]
-    mode = {"overlap": overlap, "n_sess": n_sess}     # downgraded to the plain serial loop if the warm-up fails (below)
+    state = {"i": 0, "overlap": overlap, "n_sess": n_sess, "leg": legs[0]}
 
     def step():
-        i = step_no[0]
-        step_no[0] += 1
-        overlap, n_sess = mode["overlap"], mode["n_sess"]
+        i = state["i"]
+        state["i"] += 1
+        overlap, n_sess = state["overlap"], state["n_sess"]
         b = i % nbuf
+        qb = i % nb                                              # this step's query batch
         keys_b, blk_b, doc_b, dist_b = d_views[b]
         sess, st = sessions[b % n_sess], s_scan[b % n_sess]
         if overlap and i >= nbuf:
             st.wait_event(ev_sent[b])                             # the batch that used record b before has left it
-        corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(blk_b), ptr(doc_b), ptr(d_rows[b]), ptr(dist_b),
-                             ptr(d_cnts[b]), ptr(keys_b), session=sess)
+        corpus.search_device(ptr(d_qs[qb]), nq, k, "l2", filt[state["leg"]][qb], ptr(blk_b), ptr(doc_b), ptr(d_rows[b]),
+                             ptr(dist_b), ptr(d_cnts[b]), ptr(keys_b), session=sess)
         if world > 1 and rehearsal:
             torch.cuda.synchronize()
             hg = torch.empty((world * rec,), dtype=torch.uint8)
@@ -190,152 +264,197 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    try:
-        for _ in range(args.warmup):
-            step()
-        barrier()
-    except Exception as exc:                          # never lose the run to the overlapped choreography
-        if not (mode["overlap"] or mode["n_sess"] > 1):
-            raise
-        print(f"[bench] overlapped loop failed in warm-up ({exc!r}); falling back to one batch in flight, serial "
-              f"exchange", file=sys.stderr, flush=True)
-        mode["overlap"], mode["n_sess"] = False, 1
-        torch.cuda.synchronize()
-        for _ in range(args.warmup):
-            step()
-        barrier()
-    overlap, n_sess = mode["overlap"], mode["n_sess"]
-    for sess in sessions:
-        sess.profiling(2)                             # events around the main scan launch only (the roofline kernel)
-        sess.stats_reset()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enq = time.perf_counter() - t1                  # host time to enqueue the whole run (must stay below dt)
-    barrier()
-    dt = time.perf_counter() - t1
-    st = None
-    flagged_total = 0
-    for sess in sessions:
-        one = sess.stats()
-        sess.profiling(False)
-        flagged_total += sess.screening_check(0)[0]   # K2 / seeding exactness flags over the whole run (expect 0)
-        if st is None:
-            st = one
-        else:
-            for key in ("scan_launches", "scan_ms", "scan_bytes", "scan_rows"):
-                st[key] = [a + b for a, b in zip(st[key], one[key])]
-    if world > 1:
-        ft = torch.tensor([flagged_total], dtype=torch.int64, device=dev if not rehearsal else "cpu")
-        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
-        flagged_total = int(ft.item())
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if not rehearsal else "cpu")
+    def reduce_max(v):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=dev if not rehearsal else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        return float(tt.item())
 
-    # ---- the same launch alone on the GPU: a few more batches, one in flight, same events (kernel quality, not value) ----
-    alone = None
-    if n_sess > 1:
+    def flagged():
+        total = sum(sess.screening_check(0)[0] for sess in sessions)
+        if world > 1:
+            ft = torch.tensor([total], dtype=torch.int64, device=dev if not rehearsal else "cpu")
+            dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+            total = int(ft.item())
+        return total
+
+    def timed_leg(leg, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        state["leg"] = leg
+        state["i"] = 0
+        try:
+            for _ in range(warmup):
+                step()
+            barrier()
+        except Exception as exc:                      # never lose the run to the overlapped choreography
+            if not (state["overlap"] or state["n_sess"] > 1):
+                raise
+            print(f"[bench] overlapped loop failed in warm-up ({exc!r}); falling back to one batch in flight, serial "
+                  f"exchange", file=sys.stderr, flush=True)
+            state["overlap"], state["n_sess"] = False, 1
+            torch.cuda.synchronize()
+            for _ in range(warmup):
+                step()
+            barrier()
+        for sess in sessions:
+            sess.profiling(2)                         # events around the main scan launch only (the roofline kernel)
+            sess.stats_reset()
+        before = flagged()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        t_enq = time.perf_counter() - t1              # host time to enqueue the whole run (must stay below dt)
+        barrier()
+        dt = reduce_max(time.perf_counter() - t1)
+        st = None
+        for sess in sessions:
+            one = sess.stats()
+            sess.profiling(False)
+            if st is None:
+                st = one
+            else:
+                for key in ("scan_launches", "scan_ms", "scan_bytes", "scan_rows", "scan_pairs", "unique_rows"):
+                    st[key] = [a + b for a, b in zip(st[key], one[key])]
+        sim_ok = None
+        if sim_world > 1:      # development check of the overlapped choreography on one GPU: merged == local
+            last = d_views[(state["i"] - 1) % nbuf]
+            sim_ok = bool(torch.equal(m_keys, last[0]) and torch.equal(m_blk, last[1]) and torch.equal(m_dist, last[3]))
+        return {"dt": dt, "t_enq": t_enq, "stats": st, "flagged": flagged() - before,
+                "kernel": sessions[0].last_scan_kernel(), "sim_ok": sim_ok}
+
+    def alone_stats(leg):
+        """The same launch alone on the GPU: a few more batches, one in flight, same events (kernel quality, not value)."""
+        if state["n_sess"] <= 1:
+            return None
         ctx.profiling(2)
         ctx.stats_reset()
-        for _ in range(5):
-            corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(d_views[0][1]), ptr(d_views[0][2]), ptr(d_rows[0]),
-                                 ptr(d_views[0][3]), ptr(d_cnts[0]), ptr(d_views[0][0]))
+        for j in range(5):
+            corpus.search_device(ptr(d_qs[j % nb]), nq, k, "l2", filt[leg][j % nb], ptr(d_views[0][1]), ptr(d_views[0][2]),
+                                 ptr(d_rows[0]), ptr(d_views[0][3]), ptr(d_cnts[0]), ptr(d_views[0][0]))
         torch.cuda.synchronize()
-        alone = ctx.stats()
+        a = ctx.stats()
         ctx.profiling(False)
+        return a
 
-    # ---- roofline of the dominant K1 kernel class (HIP events on the launch stream) ----
-    cls = int(np.argmax(st["scan_ms"]))
-    launches = max(1, st["scan_launches"][cls])
-    ms_avg = st["scan_ms"][cls] / launches
-    bytes_per_launch = st["scan_bytes"][cls] / launches
-    achieved = bytes_per_launch / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "vsr::mfma_scan_kernel<L2, NSTR=2, SAMPLE=false, NG=1> (K2 main pass)" if cls else
-                  "vsr::scan_kernel<L2, LPR=32, C=1, R=8, QI=1>",
-        "launch_ms": round(ms_avg, 4), "bytes_per_launch": int(bytes_per_launch),
-        "launches": int(launches),
-        "all_scan_ms": [round(v, 3) for v in st["scan_ms"]], "all_scan_bytes": [int(v) for v in st["scan_bytes"]],
-    }
+    def spot_check(leg, orc, m):
+        """Batch 0 of the leg once more, then the first m queries against the oracle (ids AND distances)."""
+        corpus.search_device(ptr(d_qs[0]), nq, k, "l2", filt[leg][0], ptr(d_views[0][1]), ptr(d_views[0][2]), ptr(d_rows[0]),
+                             ptr(d_views[0][3]), ptr(d_cnts[0]), ptr(d_views[0][0]))
+        torch.cuda.synchronize()
+        _, fl = ctx.screening_check(nq)
+        qrow, quser = batches[0]
+        ranges = [[((d - 1) * 100, 100) for d in rbac.visible_docs(int(u)).astype(np.int64)] for u in quser[:m]]
+        rows_o, dist_o, _ = orc.search_ranges("l2", x, allvec[:m], k, ranges, doc, blk)
+        got_rows = d_rows[0][:m].cpu().numpy()
+        got_dist = d_views[0][3][:m].cpu().numpy()
+        same = (got_rows == rows_o).all(axis=1) & (got_dist == dist_o.astype(np.float32)).all(axis=1)
+        hits = [len(set(a.tolist()) & set(b.tolist())) / max(1, len(b)) for a, b in zip(got_rows, rows_o)]
+        return {"queries": int(m), "ids_and_distances_identical": bool(same.all()), "recall_at_k": float(np.mean(hits)),
+                "flagged_in_batch": int(np.count_nonzero(fl))}
 
-    roofline["wall_rate"] = round(sum(st["scan_bytes"]) / dt / 1e9, 1)      # pass bytes per second of wall time, GB/s
-    if n_sess > 1:
-        roofline["note"] = (f"{n_sess} batches in flight: a launch's event-timed duration includes the time it shares the GPU "
-                            "with the other batch's kernels; `alone` is the same launch with one batch in flight")
-        if alone and alone["scan_launches"][cls]:
-            a_ms = alone["scan_ms"][cls] / alone["scan_launches"][cls]
-            a_by = alone["scan_bytes"][cls] / alone["scan_launches"][cls]
-            roofline["alone"] = {"launch_ms": round(a_ms, 4), "achieved": round(a_by / (a_ms * 1e-3) / 1e9, 1),
-                                 "frac": round(a_by / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "launches": int(alone["scan_launches"][cls])}
-    workload_tag = f"{n}x{dim} k={k} q={nq} {args.mode} gpus={world}"
-    try:      # HBM bytes per launch from a PMC pass of this same command (never measured inside the timed run)
-        with open(args.traffic) as f:
-            tr = json.load(f)
-        if tr.get("workload") == workload_tag:
-            for name, v in tr["kernels"].items():
-                main = ("mfma_scan_kernel" in name and "false" in name) if cls else ("vsr::scan_kernel" in name)
-                if main:
-                    roofline["traffic"] = int(v["hbm_bytes_per_launch"])
-                    roofline["traffic_source"] = os.path.relpath(args.traffic, ROOT) + ": " + tr["method"]
-    except (OSError, ValueError, KeyError):
-        pass
-    roofline["workload_tag"] = workload_tag
+    # ---- the timed legs ----
+    results = {}
+    for leg in legs:
+        r = timed_leg(leg, args.steps, args.warmup)
+        r["alone"] = alone_stats(leg)
+        results[leg] = r
+    head = results[legs[0]]
+    if head["flagged"] != 0 or any(r["flagged"] for r in results.values()):
+        # a flagged query is one whose exactness the screening could not prove: the serving loop must re-run it on the
+        # exact path (vsr_search / GpuShardEngine do).  A bench line that claims recall 1.0 must not contain any.
+        raise SystemExit(f"screening flagged queries in the timed region: { {m: r['flagged'] for m, r in results.items()} }")
 
+    # ---- sustained leg (N = 1 and N > 1 alike): >= --sustained-s seconds of headline steps, clocks and thermals settled ----
+    sustained = None
+    if args.sustained_s > 0:
+        per = head["dt"] / args.steps
+        s_steps = max(args.steps, int(args.sustained_s / max(per, 1e-6)))
+        s = timed_leg(legs[0], s_steps, 1)
+        if s["flagged"]:
+            raise SystemExit(f"screening flagged {s['flagged']} queries in the sustained leg")
+        sustained = {"steps": s_steps, "seconds": round(s["dt"], 3), "value": round(nq * s_steps / s["dt"], 1),
+                     "ms_per_step": round(s["dt"] / s_steps * 1e3, 4),
+                     "host_enqueue_ms_per_step": round(s["t_enq"] / s_steps * 1e3, 4)}
+
+    def leg_record(leg, r):
+        dt = r["dt"]
+        roof = roofline_of(r["stats"], dim, r["kernel"], state["n_sess"], r["alone"])
+        roof["wall_pass_bytes_rate"] = round(sum(r["stats"]["scan_bytes"]) / dt / 1e9, 1)
+        tag = f"{n}x{dim} k={k} q={nq} {leg} gpus={world}"
+        try:      # HBM bytes per launch from a PMC pass of this same command (never measured inside the timed run)
+            with open(args.traffic) as f:
+                tr = json.load(f)
+            ent = tr.get(tag)
+            if ent:
+                short = r["kernel"].split("<")[0].replace("vsr::", "")
+                for name, v in ent["kernels"].items():
+                    if short in name and ", true," not in name:          # the main launch, not the SAMPLE=true pass
+                        roof["traffic"] = int(v["hbm_bytes_per_launch"])
+                        roof["traffic_source"] = os.path.relpath(args.traffic, ROOT) + ": " + tr.get("method", "")
+                        roof["hbm_rate_measured"] = round(roof["traffic"] / (roof["launch_ms"] * 1e-3) / 1e9, 1)
+        except (OSError, ValueError, KeyError, IndexError):
+            pass
+        roof["workload_tag"] = tag
+        return {"value": round(nq * args.steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "host_enqueue_ms_per_step": round(r["t_enq"] / args.steps * 1e3, 4), "roofline": roof,
+                "screening_flagged_queries": int(r["flagged"])}
+
+    recs = {leg: leg_record(leg, r) for leg, r in results.items()}
+    main_rec = recs[legs[0]]
     out = {
         "metric": "QPS at recall@100, SIFT10M filtered-kNN (role RBAC), 1/2/4/8 MI355X",
-        "value": round(nq * args.steps / dt, 1), "unit": "queries/s",
+        "value": main_rec["value"], "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"SIFT10M-like {n}x{dim} fp32 L2 k={k}, tree RBAC 1000 users/100 roles, "
-                               f"role-partition {args.mode}, exact (recall@{k} = 1.0), {nq} queries/step",
-                   "rows": n, "dim": dim, "k": k, "queries_per_step": nq, "filter": args.mode,
-                   "sharding": f"row-range x{world}", "recall": 1.0},
-        "roofline": roofline,
+                               f"role-partition {legs[0]}, exact filtered top-k, {nq} queries/step ({nb} distinct batches)",
+                   "rows": n, "dim": dim, "k": k, "queries_per_step": nq, "filter": legs[0],
+                   "sharding": f"row-range x{world}", "recall": None, "batches_in_flight": state["n_sess"]},
+        "roofline": main_rec["roofline"],
         "setup_s": {"generate": round(t_gen, 1), "load": round(t_load, 1)},
-        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
-        "screening_flagged_queries": int(flagged_total),
+        "host_enqueue_ms_per_step": main_rec["host_enqueue_ms_per_step"],
+        "screening_flagged_queries": main_rec["screening_flagged_queries"],
     }
+    for leg in legs[1:]:
+        out[leg] = recs[leg]
+        out[leg]["workload"] = (f"same corpus, users and queries; filter = per-user row-level-security bitmap tested in "
+                                f"the distance loop (BASELINE config 4's mode)" if leg == "postfilter" else leg)
+    if sustained:
+        out["sustained"] = sustained
 
     d_keys, d_blk, d_doc, d_dist = d_views[0]         # slot 0 / session 0 from here on (everything above has drained)
     d_row, d_cnt = d_rows[0], d_cnts[0]
     # ---- latency mode (informational, N = 1): the harness's call shape, one query per call (SURVEY §8d) ----
     if world == 1 and sim_world <= 1:
         m1 = min(200, nq)
-        singles = [corpus.pack_filters([filters._keep[i]]) for i in range(m1)]
+        singles = [corpus.pack_filters([filt[legs[0]][0]._keep[i]]) for i in range(m1)]
         for i in range(8):
-            corpus.search_device(ptr(d_q[i:i + 1]), 1, k, "l2", singles[i], ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
-                                 ptr(d_cnt), ptr(d_keys))
+            corpus.search_device(ptr(d_qs[0][i:i + 1]), 1, k, "l2", singles[i], ptr(d_blk), ptr(d_doc), ptr(d_row),
+                                 ptr(d_dist), ptr(d_cnt), ptr(d_keys))
         torch.cuda.synchronize()
         tl = time.perf_counter()
         for i in range(m1):
-            corpus.search_device(ptr(d_q[i:i + 1]), 1, k, "l2", singles[i], ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
-                                 ptr(d_cnt), ptr(d_keys))
+            corpus.search_device(ptr(d_qs[0][i:i + 1]), 1, k, "l2", singles[i], ptr(d_blk), ptr(d_doc), ptr(d_row),
+                                 ptr(d_dist), ptr(d_cnt), ptr(d_keys))
         torch.cuda.synchronize()
         tl = time.perf_counter() - tl
         out["single_query_mode"] = {"queries": m1, "ms_per_query": round(tl / m1 * 1e3, 4), "qps": round(m1 / tl, 1),
-                                    "note": "one query per call, back to back on one stream (K1 path); not the headline"}
-        corpus.search_device(ptr(d_q), nq, k, "l2", filters, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
-                             ptr(d_cnt), ptr(d_keys))       # leave the batch result in place for the parity spot check
-        torch.cuda.synchronize()
+                                    "kernel": ctx.last_scan_kernel(),
+                                    "note": "one query per call, back to back on one stream; not the headline"}
 
     # ---- CPU baseline (rank 0, N = 1): the oracle, pgvector's flags, one thread, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle
         orc = Oracle("pgflags")
         m = min(args.cpu_queries, nq)
-        ranges = []
-        for u in quser[:m]:
-            docs = rbac.visible_docs(int(u)).astype(np.int64)
-            ranges.append([((d - 1) * 100, 100) for d in docs])
+        qrow, quser = batches[0]
+        qvec = allvec[:nq]
+        ranges = [[((d - 1) * 100, 100) for d in rbac.visible_docs(int(u)).astype(np.int64)] for u in quser[:m]]
         tc = time.perf_counter()
         for _ in range(max(1, args.cpu_reps)):
-            rows_o, dist_o, cnt_o = orc.search_ranges("l2", x, qvec[:m], k, ranges, doc, blk)
+            orc.search_ranges("l2", x, qvec[:m], k, ranges, doc, blk)
         cpu_s = (time.perf_counter() - tc) / max(1, args.cpu_reps)
         # the same sample fanned over host threads, one query per thread at a time (the C call releases the GIL):
         # an all-cores figure beside the single-core one (SURVEY §8d); never the headline
@@ -347,44 +466,40 @@ def main():
             list(pool.map(lambda se: orc.search_ranges("l2", x, qvec[se[0]:se[1]], k, ranges[se[0]:se[1]], doc, blk),
                           [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]))
         cpu_all_s = time.perf_counter() - ta
-        got_rows = d_row[:m].cpu().numpy()
-        got_dist = d_dist[:m].cpu().numpy()
-        ok = bool((got_rows == rows_o).all() and (got_dist == dist_o.astype(np.float32)).all())
         out["cpu_baseline"] = {
             "value": round(m / cpu_s, 2), "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"first {m} queries of the step x {max(1, args.cpu_reps)} repetitions, exact seq-scan of each "
+            "sample": f"first {m} queries of batch 0 x {max(1, args.cpu_reps)} repetitions, exact seq-scan of each "
                       f"user's role partition, {cpu_s * max(1, args.cpu_reps):.1f} s on 1 of {os.cpu_count()} host "
                       f"cores (oracle built with pgvector's flags)",
         }
         out["cpu_baseline"]["all_cores"] = {"value": round(m / cpu_all_s, 1), "unit": "queries/s", "threads": threads,
                                             "note": "same sample, queries fanned over host threads"}
-        out["parity_spot_check"] = {"queries": int(m), "ids_and_distances_identical": ok}
-    out["config"]["batches_in_flight"] = n_sess
+        checks = {leg: spot_check(leg, orc, m) for leg in legs}
+        out["parity_spot_check"] = checks[legs[0]]
+        for leg in legs[1:]:
+            out[leg]["parity_spot_check"] = checks[leg]
+        out["config"]["recall"] = checks[legs[0]]["recall_at_k"]      # measured on the sample, not asserted
+        if not all(c["ids_and_distances_identical"] for c in checks.values()):
+            print(json.dumps(out), flush=True)
+            raise SystemExit("parity spot check failed: GPU results differ from the oracle")
     if parts > 1:
         out["config"]["exchange"] = ("all-gather + merge of batch i overlapped with the scan of batch i+1 (second stream)"
-                                     if overlap else "serial (rehearsal through host memory)")
-    if sim_world > 1:      # development check of the overlapped choreography on one GPU
-        last = d_views[(step_no[0] - 1) % nbuf]      # (the latency-mode loop below does not run in this mode)
-        out["sim_world"] = {"parts": parts, "merged_equals_local": bool(torch.equal(m_keys, last[0]) and
-                                                                        torch.equal(m_blk, last[1]) and
-                                                                        torch.equal(m_dist, last[3]))}
+                                     if state["overlap"] else "serial (rehearsal through host memory)")
+    if sim_world > 1:
+        out["sim_world"] = {"parts": parts, "merged_equals_local": bool(all(r["sim_ok"] for r in results.values()))}
     if rank == 0 and world > 1 and os.environ.get("VSR_BENCH_VERIFY") == "1":
         # rehearsal check: the merged multi-rank result of a few queries against the oracle on the full corpus
         from oracle.oracle import Oracle
         orc = Oracle("pgflags")
         xf, blkf, docf = sift_like_corpus(n, dim, seed=args.seed)
         m = 8
+        qb = (state["i"] - 1) % nb
+        qrow, quser = batches[qb]
         ranges = [[((d - 1) * 100, 100) for d in rbac.visible_docs(int(u)).astype(np.int64)] for u in quser[:m]]
-        rows_o, dist_o, _ = orc.search_ranges("l2", xf, qvec[:m], k, ranges, docf, blkf)
+        rows_o, dist_o, _ = orc.search_ranges("l2", xf, allvec[qb * nq:qb * nq + m], k, ranges, docf, blkf)
         ok = bool((m_blk[:m].cpu().numpy() == blkf[rows_o]).all() and
                   (m_dist[:m].cpu().numpy() == dist_o.astype(np.float32)).all())
         out["multi_rank_parity"] = {"queries": m, "ids_and_distances_identical": ok}
-        if not ok:
-            got_b, got_d = m_blk[:m].cpu().numpy(), m_dist[:m].cpu().numpy()
-            bad = np.argwhere(got_b != blkf[rows_o])
-            print("multi-rank mismatch at", bad[:5].tolist(), "got", got_b[0, :5].tolist(), got_d[0, :5].tolist(),
-                  "want", blkf[rows_o][0, :5].tolist(), dist_o[0, :5].tolist(), "counts", m_cnt[:m].cpu().tolist(),
-                  file=sys.stderr)
     if rank == 0:
         print(json.dumps(out), flush=True)
     corpus.free()

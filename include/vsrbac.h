@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VSR_ABI_VERSION 1
+#define VSR_ABI_VERSION 2
 
 typedef struct vsr_ctx vsr_ctx;
 typedef struct vsr_corpus vsr_corpus;
@@ -150,7 +150,8 @@ int vsr_search_device_on(vsr_ctx* session, vsr_corpus* corpus, const float* d_qu
  * query when the screening's rounding error could have excluded a true result; vsr_search re-runs flagged queries on
  * the exact path itself.  After vsr_search_device the caller checks: flagged_total = flagged queries since vsr_open,
  * flags_last_call[i] != 0 = query i of the last call must be re-run with screening disabled.  Synchronises. */
-int vsr_set_screening(vsr_ctx* ctx, int enable);           /* default: enabled */
+int vsr_set_screening(vsr_ctx* ctx, int enable);           /* default: enabled; 0 also disables threshold seeding, so
+                                                              searches of that context are exact and never flag */
 int vsr_screening_check(vsr_ctx* ctx, int64_t* flagged_total, int32_t* flags_last_call, int nq);
 
 /* merge n_parts per-shard results (layout [n_parts][nq][k], as all-gathered from vsr_search_device) into the
@@ -184,11 +185,17 @@ typedef struct {
     double  select_ms;
     int64_t queries;
     double  search_ms;          /* profiling level 1: device time of whole searches, staging kernel to last output kernel */
+    /* ABI 2: what the launches HAD to do, whatever the pass structure (the honest roofline inputs) */
+    int64_t scan_pairs[2];      /* (row, query) pairs = sum over passes of rows * queries: flops = 2 * dim * pairs       */
+    int64_t unique_rows[2];     /* rows read at least once per launch, summed over launches: distinct filter parts'
+                                   rows, capped at the corpus size (exact when the parts are disjoint, e.g. classes)  */
 } vsr_stats;
 
 int vsr_profiling(vsr_ctx* ctx, int enable);      /* HIP events on the launch stream: 1 = around every launch class (scan, sample, K5), 2 = around the main scan launch only, 0 = off */
 int vsr_stats_get(vsr_ctx* ctx, vsr_stats* out);  /* synchronises, accumulates pending events */
 int vsr_stats_reset(vsr_ctx* ctx);
+/* name of the kernel instantiation the main scan launch of the session's last search resolved to ("" before any) */
+int vsr_last_scan_kernel(vsr_ctx* ctx, char* name, int name_len);
 
 /* launch-shape knobs (measurement only): blocks per launch budget, min rows per workgroup, queries per pass */
 int vsr_tune(vsr_ctx* ctx, int block_budget, int min_rows_per_block, int max_queries_per_pass);

@@ -24,7 +24,7 @@ def test_header_symbols_all_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/vsrbac.h but not exported by libvsrbac.so"
     assert sorted(_ffi.SYMBOLS) == declared, "python binding and header disagree"
-    assert vsrbac.abi_version() == 1
+    assert vsrbac.abi_version() == 2
 
 
 def test_header_compiles_as_plain_c(tmp_path):

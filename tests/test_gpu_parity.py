@@ -543,6 +543,41 @@ def test_randomized_shapes_exact(ctx, oracle, seed):
         corpus.free()
 
 
+@pytest.mark.parametrize("dim,nq", [(64, 40), (100, 300), (128, 16), (128, 32), (128, 48), (128, 130), (128, 330),
+                                     (160, 70), (192, 128), (200, 40), (256, 50)])
+def test_wide_shared_passes_exact(ctx, oracle, dim, nq):
+    """K2w (vsr_mfmaw.h): one 64-row tile per workgroup against up to 128 queries.  Shapes that hit every wave role
+    (1 / 2 / >= 3 query groups per pass, one or two groups per wave), several balanced passes per filter part (330
+    queries -> 3 x 110), 1..3 stages per tile (d = 64..192; d >= 193 stays on K2), ranges and bitmaps, a class-decomposed
+    role filter and the threshold-seeded main launch (n large enough).  Integer-valued rows: bit-exact against the oracle."""
+    import vsrbac
+    rng = np.random.default_rng(7000 + dim * 1000 + nq)
+    n, k = 70_000, 100
+    x = np.clip(np.rint(np.abs(rng.normal(0, 6, (n, dim)))), 0, 31).astype(np.float32)
+    blk, doc = _ids(n, 50)
+    corpus = ctx.load_corpus(x, blk, doc)
+    ndocs = int(doc.max())
+    # three nested roles (a chain like the tree generator's ancestors) + one disjoint role
+    own = np.array_split(rng.permutation(np.arange(1, ndocs + 1)), 4)
+    perms = [(1, int(d)) for d in own[0]] + [(2, int(d)) for d in np.concatenate(own[:2])] + \
+            [(3, int(d)) for d in np.concatenate(own[:3])] + [(4, int(d)) for d in own[3]]
+    ur = [(u, 1 + (u % 4)) for u in range(1, 41)]
+    corpus.load_rbac(ur, perms)
+    users = rng.integers(1, 41, nq)
+    q = np.clip(np.rint(np.abs(rng.normal(0, 6, (nq, dim)))), 0, 31).astype(np.float32)
+    before, _ = ctx.screening_check(0)
+    for mode in (vsrbac.RANGES, vsrbac.BITMAP):
+        filters = [corpus.filter_for_user(int(u), mode) for u in users]
+        res = corpus.search(q, k, "l2", filters)
+        for i in range(0, nq, max(1, nq // 12)):
+            mask = oracle.user_row_mask(int(users[i]), ur, perms, doc)
+            _expect_exact(oracle, res, i, "l2", x, q[i], k, doc, blk, mask)
+    res = corpus.search(q, k, "ip")                                   # unfiltered: every query shares one part
+    for i in range(0, nq, max(1, nq // 8)):
+        _expect_exact(oracle, res, i, "ip", x, q[i], k, doc, blk)
+    corpus.free()
+
+
 def vsrbac_mode(rng):
     import vsrbac
     return vsrbac.RANGES if rng.random() < 0.5 else vsrbac.BITMAP

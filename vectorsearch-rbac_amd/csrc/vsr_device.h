@@ -51,11 +51,9 @@ struct ScanParams {
     uint32_t         rw;           // rows per list tile (the corpus shape's RW)
     const uint64_t*  tau_init;     // [n_slots] seeded thresholds (sample pass), nullptr = none
     uint32_t         sample_stride;  // 1 = every tile; S > 1 = sample pass over every S-th tile of each workgroup
-    uint32_t         debug;        // measurement only: bit 0 = never append candidates (isolates the streaming/compute part)
     const uint2*     block_map;    // shared-pass launches: workgroup -> (group, block of the group); x == ~0u: idle
                                    // workgroup.  nullptr: groups own contiguous workgroup ranges (block_begin)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
-    unsigned long long* dbg;       // measurement only (VSR_DEBUG bit 1): [0] compactions, [1] appended keys, [2] tiles
 };
 
 // Per query: which partial lists to merge and where to put the result.
@@ -169,6 +167,28 @@ inline uint32_t mfma_cap_for_k(uint32_t kp)
     return cap;                    // sorted in the staging LDS: must stay <= 8192 keys (planner gate)
 }
 inline int mfma_qmax(uint32_t stride4) { (void) stride4; return 32; }
+// K2w (vsr_mfmaw.h): GEMM-shaped shared passes for rows of <= 256 floats -- one 64-row tile staged per WORKGROUP and
+// multiplied against up to 64 (128 at d <= 128) queries whose B fragments live in the four waves' registers.
+constexpr uint32_t MW_VOTE = 8;                         // workgroup tiles between two compaction votes
+__host__ __device__ inline uint32_t mfmaw_slack() { return 64u * MW_VOTE; }   // keys a query can gain between two votes
+inline uint32_t mfmaw_cap_for_k(uint32_t kp)
+{
+    uint32_t cap = 512;
+    while (cap < 2 * kp + mfmaw_slack()) cap <<= 1;
+    return cap;                    // sorted in the staging LDS (grown to cap * 8 bytes): planner gate <= 8192 keys
+}
+__host__ __device__ inline uint32_t mfmaw_stage_bytes(uint32_t cap)
+{
+    const uint32_t b = cap * 8u;
+    return b > 32768u ? b : 32768u;                     // two 64-row x 64-float stage buffers, or the sort buffer
+}
+inline size_t mfmaw_lds_bytes(uint32_t cap, int ngw)
+{
+    return (size_t) mfmaw_stage_bytes(cap) + 4 * 64 * 8 + (size_t) (64 * ngw) * 20 + 32;
+}
+inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 48; }   // d = 61 .. 192; longer rows: K2
+inline int  mfmaw_qmax(uint32_t stride4) { return stride4 <= 32 ? 128 : 64; }
+hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 64 (one wave per query) | 256 | 1024

@@ -19,6 +19,20 @@ hipError_t launch_mfma_l2(const ScanParams&, uint32_t, hipStream_t);
 hipError_t launch_mfma_ip(const ScanParams&, uint32_t, hipStream_t);
 hipError_t launch_mfma_cosine(const ScanParams&, uint32_t, hipStream_t);
 
+hipError_t launch_mfmaw_l2(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_mfmaw_ip(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_mfmaw_cosine(const ScanParams&, uint32_t, hipStream_t);
+
+hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s)
+{
+    switch (metric) {
+    case M_L2:     return launch_mfmaw_l2(p, n_blocks, s);
+    case M_IP:     return launch_mfmaw_ip(p, n_blocks, s);
+    case M_COSINE: return launch_mfmaw_cosine(p, n_blocks, s);
+    default:       return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_mfma(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s)
 {
     switch (metric) {

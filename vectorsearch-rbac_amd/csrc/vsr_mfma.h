@@ -88,8 +88,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
         ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         ctrl[qi].count = 0;
         qnl[qi] = p.q_norm2[slot];
-        if (p.dbg && p.tau_init && qi < q_count && local_block == 0)
-            atomicAdd(&p.dbg[p.tau_init[slot] == KEY_EMPTY ? 3 : 4], 1ull);
     }
     if (tid < 4) flags[tid] = 0;
     __syncthreads();
@@ -154,9 +152,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     const int lps_row = lane / MF_S, lps_chunk = lane % MF_S;
     constexpr int RPI = 64 / MF_S;
 
-    // ---- software pipeline across tiles: while the last stage of tile `it` is on the matrix cores, the row mapping of
-    // tile it+1 is already resolved and its first stage of row loads is in flight (the tile descriptor itself is
-    // fetched one step earlier still).  rowidx / rownorm are double-buffered per wave. ----
+    // the next tile's descriptor is fetched one tile ahead of its use
     auto fetch_desc = [&](uint32_t it_) -> uint2 {               // (start, nrows) of this lane's list tile, or (0, 0)
         const uint32_t sup = (it_ * MF_WAVES + wave) * ss;
         if (it_ >= iters || sup >= n_super) return make_uint2(0u, 0u);
@@ -204,36 +200,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
         if (worst >= 0 && (uint32_t) worst >= p.n_rows) atomicOr(p.err, 1u);   // cannot happen; never read past the corpus
     };
 
-// Cross-tile software pipelining (-DVSR_K2_PIPELINE=1: next tile's row mapping + first loads issued under the current
-// tile's last MFMA stage, row index / norm double-buffered per wave) is written and passes the parity suite, but is
-// ~3 % slower than the in-order loop below on the headline workload, so the in-order variant is the one shipped.
-#ifndef VSR_K2_PIPELINE
-#define VSR_K2_PIPELINE 0
-#endif
-    int buf = 0;
     int32_t myrow = -1;
     float myrn = 0.0f;
     bool have = false;
-#if VSR_K2_PIPELINE
-    myrow = resolve(fetch_desc(0));
-    myrn = myrow >= 0 ? p.norm2[myrow] : 0.0f;
-    have = __ballot(myrow >= 0) != 0;
-    if (have) {
-        rowidx[lane] = myrow;
-        issue(0, rowidx);
-    }
-#endif
-#if !VSR_K2_PIPELINE
     uint2 desc0 = fetch_desc(0);
-#endif
     uint32_t round = 0;
     for (uint32_t it = 0; it < iters; ++it) {
-        int32_t* ridx = rowidx + buf * 64;
-        float* rnrm = rownorm + buf * 64;
-#if VSR_K2_PIPELINE
-        int32_t* ridx_n = rowidx + (buf ^ 1) * 64;
-        const uint2 ndesc = fetch_desc(it + 1);                  // needed only at the last stage below
-#else
+        int32_t* ridx = rowidx;
+        float* rnrm = rownorm;
         myrow = resolve(desc0);
         myrn = myrow >= 0 ? p.norm2[myrow] : 0.0f;
         have = __ballot(myrow >= 0) != 0;
@@ -242,28 +216,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
             issue(0, ridx);
         }
         desc0 = fetch_desc(it + 1);                              // next tile's descriptor rides under this tile's work
-#endif
-#if VSR_K2_PIPELINE
-        int32_t nrow = -1;
-        float nrn = 0.0f;
-        bool nhave = false;
-#endif
-        auto prepare_next = [&]() {
-#if VSR_K2_PIPELINE
-            nrow = resolve(ndesc);
-            nhave = __ballot(nrow >= 0) != 0;
-            if (nhave) {
-                ridx_n[lane] = nrow;
-                nrn = nrow >= 0 ? p.norm2[nrow] : 0.0f;
-                issue(0, ridx_n);
-#if VSR_K2_PIPELINE == 2
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // diagnostic: no load in flight past this point
-#endif
-            }
-#endif
-        };
         if (have) {                                                            // wave-uniform
-            if (p.dbg && lane == 0) atomicAdd(&p.dbg[2], 1ull);
             rnrm[lane] = myrn;
 
             f32x4 acc[NG][4];
@@ -283,7 +236,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                     stage[row * MF_S + (lps_chunk ^ (row & 15))] = x[u];       // swizzled image
                 }
                 if (s + 1 < nstage) issue(s + 1, ridx);                        // in flight during the MFMAs
-                else prepare_next();                                           // next tile's first loads too
                 if constexpr (NSTR == 0)
                     if (s + 1 < nstage) issue_b(s + 1);
 #pragma unroll
@@ -338,7 +290,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
             for (int g = 0; g < NG; ++g) {
                 const uint32_t qi = (uint32_t) (g * MF_NQ + jq);
                 const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[qi].tau);
-                const bool qok = qi < q_count && !(p.debug & 1u);
+                const bool qok = qi < q_count;
                 // screening test in float: a value is a candidate unless it is greater than the threshold's distance
                 // (NaN values and an open / NaN threshold pass).  That admits a superset of `key < tau` (ties of the
                 // threshold distance): extra candidates are harmless, a missing one is not.  The 64-bit key is only
@@ -367,7 +319,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                         atomicOr(p.err, 2u);
                         pmask = 0;
                     }
-                    if (p.dbg && pmask) atomicAdd(&p.dbg[1], (unsigned long long) __popc(pmask));
                     uint64_t* dst = cand + (size_t) qi * cand_qstride + base;
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
@@ -377,15 +328,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                         }
                 }
             }
-        } else {
-            prepare_next();
         }
-#if VSR_K2_PIPELINE
-        myrow = nrow;
-        myrn = nrn;
-        have = nhave;
-        buf ^= 1;
-#endif
 
         if (it + 1 < iters && (it + 1) % K2_VOTE_EVERY == 0) {
             bool need = false;
@@ -401,7 +344,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                 for (uint32_t q = 0; q < q_count; ++q) {
                     const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
                     if (n > trigger) {                                         // only the buffers that are filling up
-                        if (p.dbg && tid == 0) atomicAdd(&p.dbg[0], 1ull);
                         uint64_t* cq = cand + (size_t) q * cand_qstride;
                         for (uint32_t i = tid; i < n; i += MF_THREADS) sortbuf[i] = cq[i];
                         __syncthreads();
@@ -484,10 +426,7 @@ hipError_t launch_mfma_metric(const ScanParams& p, uint32_t n_blocks, hipStream_
         if (ng == 2) return sample ? launch(mfma_scan_kernel<METRIC, 0, true, 2>) : launch(mfma_scan_kernel<METRIC, 0, false, 2>);
         return sample ? launch(mfma_scan_kernel<METRIC, 0, true, 1>) : launch(mfma_scan_kernel<METRIC, 0, false, 1>);
     }
-    if (nstage <= 2) {
-        if (ng == 2) return sample ? launch(mfma_scan_kernel<METRIC, 2, true, 2>) : launch(mfma_scan_kernel<METRIC, 2, false, 2>);
-        return sample ? launch(mfma_scan_kernel<METRIC, 2, true, 1>) : launch(mfma_scan_kernel<METRIC, 2, false, 1>);
-    }
+    // rows of <= 192 floats run on K2w (vsr_mfmaw.h); what reaches this kernel with <= 4 stages are rows of 193 .. 256 floats
     if (ng == 2) return sample ? launch(mfma_scan_kernel<METRIC, 4, true, 2>) : launch(mfma_scan_kernel<METRIC, 4, false, 2>);
     return sample ? launch(mfma_scan_kernel<METRIC, 4, true, 1>) : launch(mfma_scan_kernel<METRIC, 4, false, 1>);
 }

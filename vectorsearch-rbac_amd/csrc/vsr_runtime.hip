@@ -4,6 +4,7 @@
 #include "vsr_device.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -141,15 +142,37 @@ struct vsr_ctx {
     int min_shared_rows = 2048;    // rows per workgroup of a shared pass (VSR_MIN_SHARED_ROWS)
     int max_qb = 16;               // queries per shared pass.  32 (two MFMA query groups) does not pay at d = 128; the planner
                                    // picks it by itself for long rows when the query groups fill it (make_plan)
-    uint32_t debug = 0;            // VSR_DEBUG bits (measurement only)
+    uint32_t debug = 0;            // VSR_DEBUG != 0: vsr_stats_get prints host-side timings (measurement only)
     double extra_ms[2] = {0, 0};   // sample scan, seed select (profiling only)
     double host_us[3] = {0, 0, 0}; // VSR_DEBUG: host time in make_plan / waiting for the staging buffer / whole search_impl
     long   host_calls = 0;
-    unsigned long long* d_dbg = nullptr;
+    std::string last_kernel;       // main scan kernel of the last search (vsr_last_scan_kernel)
     bool no_classes = false;       // VSR_NO_CLASSES=1: scan role partitions whole (A/B measurements)
     bool max_qb_set = false;       // VSR_MAX_QB / vsr_tune chose the queries per pass: the planner does not override it
     bool no_xcd_map = false;       // VSR_NO_XCD_MAP=1: workgroups in pass order instead of XCD-aware bundles (A/B)
     bool no_mq = false;            // VSR_NO_MQ=1: keep shared passes on K1 (A/B measurements)
+    bool no_wide = false;          // VSR_NO_WIDE=1: shared passes on K2 (wave-private tiles) instead of K2w (A/B)
+
+    ~vsr_ctx()                     // also runs on vsr_open's error returns: nothing allocated so far is leaked
+    {
+        for (auto& ep : pending) {
+            (void) hipEventDestroy(ep.a);
+            (void) hipEventDestroy(ep.b);
+        }
+        for (auto ev : event_pool) (void) hipEventDestroy(ev);
+        d_desc.release();
+        d_partial.release();
+        d_cand.release();
+        d_flags.release();
+        d_tau.release();
+        d_out.release();
+        d_misc.release();
+        h_desc.release();
+        h_out.release();
+        if (desc_done) (void) hipEventDestroy(desc_done);
+        if (d_flag_total) (void) hipFree(d_flag_total);
+        if (own_stream) (void) hipStreamDestroy(own_stream);
+    }
 };
 
 struct vsr_filter {
@@ -201,6 +224,8 @@ struct vsr_corpus {
     std::vector<uint32_t> doc_class;                 // per document
     std::vector<std::vector<uint64_t>> class_sig;    // per class
     std::vector<vsr_filter*> class_filters;          // per class, built on first use (RANGES, owned by the corpus)
+
+    ~vsr_corpus();                 // frees the device arrays and cached filters (also on vsr_corpus_load's error returns)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -252,6 +277,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_MIN_ROWS_PER_BLOCK"))) ctx->min_rows_per_block = std::max(1, atoi(env));
     if ((env = getenv("VSR_MAX_QB"))) { ctx->max_qb = std::max(1, atoi(env)); ctx->max_qb_set = true; }
     if ((env = getenv("VSR_NO_MQ"))) ctx->no_mq = atoi(env) != 0;
+    if ((env = getenv("VSR_NO_WIDE"))) ctx->no_wide = atoi(env) != 0;
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
@@ -270,23 +296,6 @@ extern "C" int vsr_close(vsr_ctx* ctx)
     if (!ctx) return VSR_OK;
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
-    for (auto& ep : ctx->pending) {
-        (void) hipEventDestroy(ep.a);
-        (void) hipEventDestroy(ep.b);
-    }
-    for (auto ev : ctx->event_pool) (void) hipEventDestroy(ev);
-    ctx->d_desc.release();
-    ctx->d_partial.release();
-    ctx->d_cand.release();
-    ctx->d_flags.release();
-    ctx->d_tau.release();
-    ctx->d_out.release();
-    ctx->d_misc.release();
-    ctx->h_desc.release();
-    ctx->h_out.release();
-    if (ctx->desc_done) (void) hipEventDestroy(ctx->desc_done);
-    if (ctx->d_flag_total) (void) hipFree(ctx->d_flag_total);
-    if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VSR_OK;
 }
@@ -376,10 +385,7 @@ extern "C" int vsr_stats_get(vsr_ctx* ctx, vsr_stats* out)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     drain_events(ctx);
     *out = ctx->stats;
-    if (ctx->d_dbg) {
-        unsigned long long h[5] = {0, 0, 0, 0, 0};
-        HIPCHK(hipMemcpy(h, ctx->d_dbg, sizeof h, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemset(ctx->d_dbg, 0, 64));
+    if (ctx->debug) {              // VSR_DEBUG=1: host-side timing of the searches since the last call (stderr)
         fprintf(stderr, "[vsr debug] sample_scan_ms=%.3f seed_select_ms=%.3f\n", ctx->extra_ms[0], ctx->extra_ms[1]);
         ctx->extra_ms[0] = ctx->extra_ms[1] = 0;
         if (ctx->host_calls)
@@ -388,8 +394,6 @@ extern "C" int vsr_stats_get(vsr_ctx* ctx, vsr_stats* out)
                     ctx->host_calls);
         ctx->host_us[0] = ctx->host_us[1] = ctx->host_us[2] = 0;
         ctx->host_calls = 0;
-        fprintf(stderr, "[vsr debug] compactions=%llu appended=%llu tiles=%llu seeds_empty=%llu seeds_set=%llu\n", h[0], h[1],
-                h[2], h[3], h[4]);
     }
     return VSR_OK;
 }
@@ -413,12 +417,16 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
     if (!c) return VSR_OK;
     (void) hipSetDevice(c->ctx->device);
     (void) hipStreamSynchronize(c->ctx->stream);
-    drop_cached_filters(c);
-    void* ptrs[] = {c->d_rows, c->d_norm2, c->d_norm2_max, c->d_block, c->d_doc, c->d_orig, c->d_row_docidx, c->d_doc_mask};
-    for (void* p : ptrs)
-        if (p) (void) hipFree(p);
     delete c;
     return VSR_OK;
+}
+
+vsr_corpus::~vsr_corpus()
+{
+    drop_cached_filters(this);
+    void* ptrs[] = {d_rows, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
+    for (void* p : ptrs)
+        if (p) (void) hipFree(p);
 }
 
 extern "C" int64_t vsr_corpus_rows(const vsr_corpus* c) { return c ? c->n : 0; }
@@ -917,7 +925,8 @@ struct Plan {
     uint32_t                 n_blocks = 0;
     int                      qi = 1;         // K1 sub-batch width (1 or 4)
     bool                     mq = false;     // shared passes run on K1m (vsr_mq.h)
-    bool                     k2 = false;     // shared passes run on K2 (MFMA screening) + K5r
+    bool                     k2 = false;     // shared passes run on K2 / K2w (MFMA screening) + K5r
+    bool                     k2w = false;    // ... on K2w: workgroup-shared row tiles, up to 128 queries per pass (vsr_mfmaw.h)
     uint32_t                 keep = 0;       // partial list length kp (K2: 2k screening survivors; else k)
     uint32_t                 rerank_base = 0;  // K2: first partial list holding the per-query screening survivors
     uint32_t                 n_scan_lists = 0;
@@ -935,12 +944,15 @@ struct Plan {
     uint32_t                 n_launch = 0;   // workgroups of the main launch (= block_map.size() when mapped)
     int64_t                  scan_rows = 0;
     int64_t                  scan_bytes = 0;
+    int64_t                  scan_pairs = 0;   // sum over passes of rows * queries
+    int64_t                  unique_rows = 0;  // distinct filter parts' rows (capped at the corpus size)
 
     void reset()                             // keeps the vectors' capacity: one plan per batch, no allocation once warm
     {
         q_slots.clear(); groups.clear(); list_ids.clear(); block_map.clear(); n_launch = 0; sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
-        n_blocks = 0; qi = 1; mq = false; k2 = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
+        n_blocks = 0; qi = 1; mq = false; k2 = false; k2w = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
         n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0; sel_wave = false;
+        scan_pairs = 0; unique_rows = 0;
     }
 };
 
@@ -961,11 +973,13 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
 
     // (filter part, query slot) items grouped by part: group ids in first-seen order, then a counting sort (stable, so
     // the slots of a part stay ascending).  No comparison sort, no per-query allocation: the planner runs once per batch.
-    static thread_local uint64_t epoch = 0;
+    // plan marks live in the (shared) filters, so the epoch must be unique across host threads: a corpus handed from one
+    // thread to another must never meet a stale mark that equals the new thread's counter
+    static std::atomic<uint64_t> g_epoch{0};
+    const uint64_t epoch = g_epoch.fetch_add(1, std::memory_order_relaxed) + 1;
     static thread_local std::vector<PassItem> raw, items;
     static thread_local std::vector<uint32_t> gid, gcount;
     static thread_local std::vector<const vsr_filter*> gpart;
-    ++epoch;
     raw.clear(); gid.clear(); gcount.clear(); gpart.clear();
     const bool decompose = nq >= 32 && !ctx->no_classes;
     uint32_t null_group = 0xFFFFFFFFu;
@@ -1009,13 +1023,21 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         for (size_t i = 0; i < raw.size(); ++i) items[gcount[gid[i]]++] = raw[i];
     }
 
+    for (const vsr_filter* part : gpart) plan.unique_rows += part ? part->scanned_rows : c->n;
+    plan.unique_rows = std::min<int64_t>(plan.unique_rows, c->n);
+
     const bool mq_ok = mq_supported(c->dim) && mq_qmax(c->dim) >= 4 && !ctx->no_mq;
-    // K2: matrix-core screening keeps 2k (>= 32) candidates per query, K5r re-ranks them exactly
+    // K2 / K2w: matrix-core screening keeps 2k (>= 32) candidates per query, K5r re-ranks them exactly
     const uint32_t keep = (uint32_t) std::max(2 * k, 32);
-    const bool k2_ok = allow_screening && ctx->screening && c->k2_safe && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
-                       mfma_cap_for_k(keep) <= 8192 && ctx->max_qb >= 16 && mfma_lds_bytes(c->stride4) <= 150 * 1024;
-    int qmax = k2_ok ? std::min(ctx->max_qb, mfma_qmax(c->stride4)) : std::min(ctx->max_qb, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
-    if (k2_ok && !ctx->max_qb_set && qmax >= 16 && c->stride4 > 64) {
+    const bool k2_any = allow_screening && ctx->screening && c->k2_safe && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
+                        ctx->max_qb >= 16;
+    const bool k2w_ok = k2_any && mfmaw_supported(c->stride4) && mfmaw_cap_for_k(keep) <= 8192 && !ctx->no_wide;
+    const bool k2_ok = k2w_ok || (k2_any && mfma_cap_for_k(keep) <= 8192 && mfma_lds_bytes(c->stride4) <= 150 * 1024);
+    int qmax;
+    if (k2w_ok) qmax = ctx->max_qb_set ? std::min(ctx->max_qb, mfmaw_qmax(c->stride4)) : mfmaw_qmax(c->stride4);
+    else if (k2_ok) qmax = std::min(ctx->max_qb_set ? ctx->max_qb : 16, mfma_qmax(c->stride4));
+    else qmax = std::min(ctx->max_qb_set ? ctx->max_qb : 16, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
+    if (k2_ok && !k2w_ok && !ctx->max_qb_set && qmax >= 16 && c->stride4 > 64) {
         // long rows (d > 256): a pass costs mostly its row bytes, so two 16-query MFMA groups per pass (half the passes)
         // pay off -- but only when the query groups fill them (an unfiltered 1000-query batch: 17 % less time at
         // d = 768; role partitions with ~25 queries per class: 2.7x more, the second group would be mostly padding)
@@ -1027,9 +1049,9 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         }
         if (slots && used * 10 >= slots * 9) qmax = std::min(32, mfma_qmax(c->stride4));
     }
-    qmax = qmax >= 4 ? qmax / 4 * 4 : 1;
+    qmax = k2w_ok ? std::max(16, qmax / 16 * 16) : qmax >= 4 ? qmax / 4 * 4 : 1;
 
-    struct Pass { const vsr_filter* f; uint32_t q_off, q_count; int64_t rows; uint32_t n_tiles; };
+    struct Pass { const vsr_filter* f; uint32_t q_off, q_count; int64_t rows; uint32_t n_tiles; int64_t cost; };
     static thread_local std::vector<Pass> passes;
     passes.clear();
     uint32_t widest = 1;
@@ -1037,14 +1059,25 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         size_t e = s;
         while (e < items.size() && items[e].part == items[s].part) ++e;
         const vsr_filter* f = items[s].part;
+        // K2w: a part seen by more queries than one pass holds is cut into equal passes (330 queries -> 3 x 110, not
+        // 128 + 128 + 74), each a whole number of 16-query MFMA groups
+        size_t per = (size_t) qmax;
+        if (k2w_ok && e - s > (size_t) qmax) {
+            const size_t n_pass = (e - s + (size_t) qmax - 1) / (size_t) qmax;
+            per = std::min<size_t>((size_t) qmax, ((e - s + n_pass - 1) / n_pass + 15) / 16 * 16);
+        }
         for (size_t b = s; b < e;) {
-            const uint32_t cnt = (uint32_t) std::min<size_t>(e - b, (size_t) qmax);
+            const uint32_t cnt = (uint32_t) std::min<size_t>(e - b, per);
             Pass pd;
             pd.f = f;
             pd.q_off = (uint32_t) plan.q_slots.size();
             pd.q_count = cnt;
             pd.rows = f ? f->scanned_rows : c->n;
             pd.n_tiles = f ? f->n_tiles : (uint32_t) ((c->n + c->shape.rw - 1) / c->shape.rw);
+            // relative cost of a row of this pass: K2w passes are bound by the row stream up to ~3 query groups and by
+            // the matrix pipe beyond (a 64-row tile costs 4 * groups * d/4 MFMAs), so fat passes get more workgroups
+            const int64_t groups = (cnt + 15) / 16;
+            pd.cost = std::max<int64_t>(pd.rows, 1) * (k2w_ok ? std::max<int64_t>(32, 10 * groups) : 32);
             for (uint32_t i = 0; i < cnt; ++i) plan.q_slots.push_back(items[b + i].slot);
             passes.push_back(pd);
             widest = std::max(widest, cnt);
@@ -1056,12 +1089,17 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     plan.qi = widest > 1 ? 4 : 1;
     plan.qmax = plan.qi == 1 ? 1 : (widest + 3) / 4 * 4;
     plan.k2 = plan.qi == 4 && k2_ok;
+    plan.k2w = plan.k2 && k2w_ok;
     plan.mq = plan.qi == 4 && mq_ok && !plan.k2;
     plan.keep = plan.k2 ? keep : (uint32_t) k;
-    if (plan.k2) plan.qmax = plan.qmax > 16 ? 32 : 16;
+    if (plan.k2w) plan.qmax = plan.qmax > 64 ? 128 : 64;    // query slots per workgroup: one or two groups per wave
+    else if (plan.k2) plan.qmax = plan.qmax > 16 ? 32 : 16;
 
-    int64_t total_rows = 0;
-    for (auto& p : passes) total_rows += std::max<int64_t>(p.rows, 1);
+    int64_t total_rows = 0, total_cost = 0;
+    for (auto& p : passes) {
+        total_rows += std::max<int64_t>(p.rows, 1);
+        total_cost += p.cost;
+    }
     // Workgroups per launch: 4 per CU (two resident at a time), and for big shared-pass launches one per ~13k scanned
     // rows up to 16 per CU -- finer blocks even out the passes' very different lengths over the chip (10M rows, 1000
     // queries: main launch alone 2.38 -> 2.12 ms with 8 per CU).  The sample launch then keeps ~2 workgroups per CU.
@@ -1081,7 +1119,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     loff.assign((size_t) nq + 1, 0);
     for (auto& p : passes) {
         if (p.n_tiles == 0 || p.rows == 0) continue;       // empty filter part: nothing to scan
-        int64_t nb = (std::max<int64_t>(p.rows, 1) * budget + total_rows - 1) / total_rows;
+        int64_t nb = (int64_t) (((__int128) p.cost * budget + total_cost - 1) / total_cost);
         const int64_t min_rows = p.q_count > 1 ? std::max<int64_t>(ctx->min_rows_per_block, ctx->min_shared_rows) : ctx->min_rows_per_block;
         nb = std::min<int64_t>(nb, std::max<int64_t>(1, p.rows / min_rows));   // shared passes need rows to prune on
         nb = std::min<int64_t>(nb, std::max<uint32_t>(1, p.n_tiles));
@@ -1107,6 +1145,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         plan.n_blocks_s += gs.n_blocks;
         plan.n_partial_s += gs.n_blocks * p.q_count;
         plan.scan_rows += p.rows;
+        plan.scan_pairs += p.rows * (int64_t) p.q_count;
         plan.scan_bytes += p.rows * (int64_t) c->dim * 4 + (g.bitmap ? (p.rows + 7) / 8 : 0) + (int64_t) p.q_count * k * 12 +
                            (plan.k2 ? p.rows * 4 : 0);     // K2 also reads |row|^2
     }
@@ -1227,6 +1266,26 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// the instantiation the main scan launch of a plan resolves to (bench.py reports it beside the roofline)
+static std::string scan_kernel_name(const Plan& plan, const vsr_corpus* c, int metric)
+{
+    static const char* mname[] = {"L2", "IP", "COSINE", "L1"};
+    char buf[160];
+    const uint32_t nstage = (c->stride4 + 15) / 16;
+    if (plan.k2w)
+        snprintf(buf, sizeof buf, "vsr::mfma_wide_kernel<%s, NSTR=%u, SAMPLE=false, NGW=%d> (K2w)", mname[metric], nstage,
+                 plan.qmax > 64 ? 2 : 1);
+    else if (plan.k2)
+        snprintf(buf, sizeof buf, "vsr::mfma_scan_kernel<%s, NSTR=%d, SAMPLE=false, NG=%d> (K2)", mname[metric],
+                 nstage > 4 ? 0 : 4, plan.qmax > 16 ? 2 : 1);
+    else if (plan.mq)
+        snprintf(buf, sizeof buf, "vsr::mq_scan_kernel<%s, SAMPLE=false> (K1m)", mname[metric]);
+    else
+        snprintf(buf, sizeof buf, "vsr::scan_kernel<%s, LPR=%d, C=%d, R=%d, QI=%d> (K1)", mname[metric], c->shape.lpr,
+                 c->shape.c, c->shape.r, plan.qi);
+    return buf;
+}
+
 // Shared by the host and device entry points.  d_queries == nullptr: queries come from `h_queries`.
 // `ctx` is the session the search runs in (stream, workspaces, counters): the corpus's own context, or another context
 // of the same device (vsr_search_device_on) so that two batches over one corpus can be in flight at once.
@@ -1333,21 +1392,12 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     sp.partial = ctx->d_partial.as<uint64_t>();
     sp.kp = kp;
     sp.k = kp;
-    sp.cap = plan.k2 ? mfma_cap_for_k(kp) : scan_cap_for_k((int) kp, c->dim);
+    sp.cap = plan.k2w ? mfmaw_cap_for_k(kp) : plan.k2 ? mfma_cap_for_k(kp) : scan_cap_for_k((int) kp, c->dim);
     sp.qmax = plan.qmax;
     sp.rw = (uint32_t) c->shape.rw;
     sp.cand = nullptr;
-    sp.debug = ctx->debug;
     sp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;    // bounds-guard word (checked by vsr_screening_check)
     sp.block_map = nullptr;
-    sp.dbg = nullptr;
-    if (ctx->debug & 2u) {
-        if (!ctx->d_dbg) {
-            HIPCHK(hipMalloc(&ctx->d_dbg, 64));
-            HIPCHK(hipMemset(ctx->d_dbg, 0, 64));
-        }
-        sp.dbg = ctx->d_dbg;
-    }
     if (plan.mq || plan.k2) {
         if ((rc = ctx->d_cand.reserve(std::max<size_t>(8, (size_t) plan.n_scan_lists * cand_pitch(sp.cap) * sizeof(uint64_t))))) return rc;
         sp.cand = ctx->d_cand.as<uint64_t>();
@@ -1391,10 +1441,17 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     // m-th best of a 1/SEED_STRIDE sample: mean lambda = kp / SEED_STRIDE rows of the true top-kp fall into the
     // sample; lambda + 6 sigma + 4 makes a too-tight seed a ~1e-8 event (and a detected one: K5 / K5r flag it).
     // The m-th best of the whole sample only involves the m best of every sample list, so those lists are short.
-    const double lambda = (double) kp / SEED_STRIDE;
+    // Every sample workgroup visits at least one 64-row tile, so a pass cut into many workgroups is sampled more densely
+    // than 1 / SEED_STRIDE: lambda uses the densest pass's fraction (a larger m only loosens the seed).
+    double frac = 1.0 / SEED_STRIDE;
+    for (const ScanGroup& g : plan.groups_s) {
+        const double rows = (double) g.n_tiles * c->shape.rw;
+        if (rows > 0) frac = std::max(frac, std::min(1.0, 64.0 * g.n_blocks / rows));
+    }
+    const double lambda = (double) kp * frac;
     const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
     constexpr uint32_t SEED_LIST = 64;                      // keys a sample-pass workgroup publishes per query (one tile: no selection)
-    const bool seed = allow_screening && ctx->seeding && (plan.k2 || plan.mq) && plan.n_blocks > 0 &&
+    const bool seed = allow_screening && ctx->screening && ctx->seeding && (plan.k2 || plan.mq) && plan.n_blocks > 0 &&
                       seed_m <= SEED_LIST && kp >= SEED_LIST &&
                       plan.scan_rows >= ctx->seed_min_rows &&
                       plan.scan_rows / (int64_t) std::max<size_t>(1, plan.groups.size()) >= ctx->seed_min_pass_rows;
@@ -1410,7 +1467,8 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
             HIPCHK(hipEventRecord(a0, ctx->stream));
         }
         sp.kp = sp.k = SEED_LIST;
-        if (plan.k2) HIPCHK(launch_mfma(sp, metric, plan.n_blocks_s, ctx->stream));
+        if (plan.k2w) HIPCHK(launch_mfmaw(sp, metric, plan.n_blocks_s, ctx->stream));
+        else if (plan.k2) HIPCHK(launch_mfma(sp, metric, plan.n_blocks_s, ctx->stream));
         else HIPCHK(launch_mq(sp, metric, plan.n_blocks_s, ctx->stream));
         sp.kp = sp.k = kp;
         if (a0) {
@@ -1446,15 +1504,19 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         }
         if (!plan.block_map.empty() && !ctx->no_xcd_map) sp.block_map = reinterpret_cast<const uint2*>(ds + off_bm);
         const uint32_t launch_blocks = sp.block_map ? plan.n_launch : plan.n_blocks;
-        if (plan.k2) HIPCHK(launch_mfma(sp, metric, launch_blocks, ctx->stream));
+        if (plan.k2w) HIPCHK(launch_mfmaw(sp, metric, launch_blocks, ctx->stream));
+        else if (plan.k2) HIPCHK(launch_mfma(sp, metric, launch_blocks, ctx->stream));
         else if (plan.mq) HIPCHK(launch_mq(sp, metric, launch_blocks, ctx->stream));
         else HIPCHK(launch_scan(sp, metric, c->dim, plan.qi, plan.n_blocks, ctx->stream));
         if (e0) {
             HIPCHK(hipEventRecord(e1, ctx->stream));
             ctx->pending.push_back({e0, e1, cls});
         }
+        ctx->last_kernel = scan_kernel_name(plan, c, metric);
         ctx->stats.scan_bytes[cls] += plan.scan_bytes;
         ctx->stats.scan_rows[cls] += plan.scan_rows;
+        ctx->stats.scan_pairs[cls] += plan.scan_pairs;
+        ctx->stats.unique_rows[cls] += plan.unique_rows;
     }
 
     sel.k = kp;
@@ -1609,6 +1671,13 @@ extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, 
             out_cnt[redo[j]] = reinterpret_cast<int32_t*>(h + o_cnt)[j];
         }
     }
+    return VSR_OK;
+}
+
+extern "C" int vsr_last_scan_kernel(vsr_ctx* ctx, char* name, int name_len)
+{
+    if (!ctx || !name || name_len < 1) return fail(VSR_ERR_INVALID, "vsr_last_scan_kernel: bad argument");
+    snprintf(name, (size_t) name_len, "%s", ctx->last_kernel.c_str());
     return VSR_OK;
 }
 

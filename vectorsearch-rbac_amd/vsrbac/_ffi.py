@@ -18,7 +18,8 @@ class VsrError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("scan_launches", C.c_int64 * 2), ("scan_ms", C.c_double * 2), ("scan_bytes", C.c_int64 * 2),
                 ("scan_rows", C.c_int64 * 2), ("select_launches", C.c_int64), ("select_ms", C.c_double),
-                ("queries", C.c_int64), ("search_ms", C.c_double)]
+                ("queries", C.c_int64), ("search_ms", C.c_double),
+                ("scan_pairs", C.c_int64 * 2), ("unique_rows", C.c_int64 * 2)]
 
 
 # every symbol include/vsrbac.h declares: name -> (restype, argtypes)
@@ -56,6 +57,7 @@ SYMBOLS = {
     "vsr_profiling": (_i, [_vp, _i]),
     "vsr_stats_get": (_i, [_vp, C.POINTER(Stats)]),
     "vsr_stats_reset": (_i, [_vp]),
+    "vsr_last_scan_kernel": (_i, [_vp, C.c_char_p, _i]),
     "vsr_tune": (_i, [_vp, _i, _i, _i]),
 }
 

@@ -71,6 +71,12 @@ class Context:
     def stats_reset(self):
         check(self._lib.vsr_stats_reset(self._h))
 
+    def last_scan_kernel(self):
+        """Kernel instantiation the main scan launch of this session's last search resolved to."""
+        buf = C.create_string_buffer(200)
+        check(self._lib.vsr_last_scan_kernel(self._h, buf, 200))
+        return buf.value.decode()
+
     def set_screening(self, enable=True):
         """Allow the MFMA screening + exact re-rank path (K2/K5r) for shared passes."""
         check(self._lib.vsr_set_screening(self._h, int(bool(enable))))

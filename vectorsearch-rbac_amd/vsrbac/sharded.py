@@ -14,6 +14,8 @@ import ctypes
 
 import numpy as np
 
+from ._ffi import VsrError
+
 
 def shard_bounds(n_rows, world, rank, align=1):
     """Rows [lo, hi) of rank `rank`; boundaries rounded down to `align` rows so documents stay whole."""
@@ -95,17 +97,33 @@ class GpuShardEngine:
                 idx = torch.from_numpy(redo).to(self.device)
                 sub = {n: torch.empty((redo.size,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
                        for n, t in out.items()}          # (pack is attached after the fallback)
-                fl = None if filters is None else [filters[i] for i in redo] if not hasattr(filters, "_h") else filters
+                fl = self._subset_filters(filters, redo)
                 self._keep = self.corpus.search_device(self._p(q[idx].contiguous()), int(redo.size), k, metric, fl,
                                                        self._p(sub["block"]), self._p(sub["doc"]), None,
                                                        self._p(sub["dist"]), self._p(sub["counts"]), self._p(sub["keys"]))
-                self.ctx.synchronize()
+                # screening AND threshold seeding are off for the re-run (vsr_set_screening): it is the exact path and
+                # cannot flag again; anything else is a library fault and must not be published
+                _, again = self.ctx.screening_check(int(redo.size))
+                if again.any():
+                    raise VsrError(4, f"{int(again.sum())} queries still flagged after the exact re-run")
                 for n in out:
                     out[n][idx] = sub[n]
             finally:
                 self.ctx.set_screening(True)
         out["pack"] = pack
         return out
+
+    @staticmethod
+    def _subset_filters(filters, redo):
+        """The filters of the queries `redo`, in whatever form the caller passed them: None, one shared Filter, a list
+        of Filters, or a packed C array (Corpus.pack_filters; the handles stay owned by the original array)."""
+        if filters is None or hasattr(filters, "_h"):
+            return filters
+        if isinstance(filters, ctypes.Array):
+            sub = (ctypes.c_void_p * len(redo))(*[filters[int(i)] for i in redo])
+            sub._keep = filters
+            return sub
+        return [filters[int(i)] for i in redo]
 
     def finalize(self, local):
         return local["block"], local["doc"], local["dist"], local["counts"]
