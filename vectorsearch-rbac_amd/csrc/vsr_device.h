@@ -6,6 +6,8 @@
 namespace vsr {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;   // native vector: loads as one dwordx4 and stays in registers
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16; // A / B fragment of v_mfma_f32_16x16x32_bf16
 
 constexpr uint64_t KEY_EMPTY = ~0ull;     // sorts after every real key (NaN keys included)
 constexpr int      SCAN_THREADS = 512;    // 8 waves per workgroup
@@ -53,6 +55,10 @@ struct ScanParams {
     uint32_t         sample_stride;  // 1 = every tile; S > 1 = sample pass over every S-th tile of each workgroup
     const uint2*     block_map;    // shared-pass launches: workgroup -> (group, block of the group); x == ~0u: idle
                                    // workgroup.  nullptr: groups own contiguous workgroup ranges (block_begin)
+    // K2w screening planes (bf16 hi / mid split of every element, vsr_planes.h layout): corpus rows and query slots
+    const uint4*     scr;          // [n_rows][pstride4] 16-byte chunks
+    const uint4*     q_scr;        // [n_slots][pstride4]
+    uint32_t         pstride4;     // 16-byte chunks per plane row = 16 * ceil(dim / 64)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
 };
 
@@ -117,6 +123,7 @@ struct RerankParams {
     float*             out_dist;
     uint64_t*          out_keys;
     int32_t*           out_count;
+    float              err_g;          // relative error bound of the screening dot product: |dot_s - dot| <= err_g |x| |q|
     int                seeded;         // thresholds were seeded from a sample: also check completeness
     const uint64_t*    tau_init;       // [n_slots] the seeds (bound on every excluded row when the list is not full)
     int32_t*           out_flags;      // [n_queries] by out_slot: 1 = screening gap inside the error bound
@@ -189,6 +196,14 @@ inline size_t mfmaw_lds_bytes(uint32_t cap, int ngw)
 inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 48; }   // d = 61 .. 192; longer rows: K2
 inline int  mfmaw_qmax(uint32_t stride4) { return stride4 <= 32 ? 128 : 64; }
 hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
+// Screening planes: element x = hi + mid + e with hi = bf16(x), mid = bf16(x - hi) (|e| <= 2^-18 |x|).  A plane row holds,
+// for every 64-float stage s, 8 chunks of 8 hi values followed by 8 chunks of 8 mid values (16 bytes each, zero padded):
+// the same 256 bytes per row and stage as the fp32 image, but ready for v_mfma_f32_16x16x32_bf16 (16x the fp32 rate).
+inline uint32_t plane_stride4(int dim) { return 16u * (uint32_t) ((dim + 63) / 64); }
+hipError_t launch_split_planes(const float4* rows, uint32_t n_rows, uint32_t stride4, int dim, uint4* scr, uint32_t pstride4,
+                               uint32_t* any_mid, hipStream_t s);
+// relative error bound of the plane product  xh*qh + xh*qm + xm*qh  accumulated in fp32 over `dim` elements
+inline float plane_err_g(int dim) { return 3.0f * 3.8146973e-6f + (float) (3 * dim + 8) * 5.9604645e-8f; }
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 64 (one wave per query) | 256 | 1024
@@ -204,6 +219,8 @@ struct StageParams {
     float*       q_dst;            // nq x qfloats, zero padded
     uint32_t     dim, qfloats, nq;
     float*       q_norm2;          // [nq]
+    uint4*       q_scr;            // [nq][pstride4] bf16 hi / mid planes of the padded queries (nullptr: not needed)
+    uint32_t     pstride4;
     int32_t*     flags;            // [nq] <- 0
     uint64_t*    tau;              // [nq] <- KEY_EMPTY (no seed)
 };

@@ -1,4 +1,5 @@
 // vsr_kernels.hip — K5 (top-k select / merge) and the small support kernels of the filtered k-NN path.
+#include <algorithm>
 #include "vsr_device.h"
 #include "vsr_topk.h"
 
@@ -464,6 +465,64 @@ hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------------------------------------
+// Screening planes (K2w): 8 consecutive floats -> one chunk of 8 bf16 "hi" values and one of 8 "mid" values
+// (hi = bf16(x), mid = bf16(x - hi); round to nearest even; x - hi is exact in fp32).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& mid)
+{
+    unsigned short h[8], m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 bh = (__bf16) x[j];
+        const float r = x[j] - (float) bh;
+        const __bf16 bm = (__bf16) r;
+        h[j] = __builtin_bit_cast(unsigned short, bh);
+        m[j] = __builtin_bit_cast(unsigned short, bm);
+    }
+    hi = make_uint4(h[0] | (uint32_t) h[1] << 16, h[2] | (uint32_t) h[3] << 16, h[4] | (uint32_t) h[5] << 16, h[6] | (uint32_t) h[7] << 16);
+    mid = make_uint4(m[0] | (uint32_t) m[1] << 16, m[2] | (uint32_t) m[3] << 16, m[4] | (uint32_t) m[5] << 16, m[6] | (uint32_t) m[7] << 16);
+}
+
+// planes of one padded fp32 row (stride4 float4, zeros past dim): item = (stage, chunk c < 8) covers floats 64 s + 8 c ..
+__device__ __forceinline__ bool split_row_item(const float4* row, uint32_t stride4, uint4* prow, uint32_t item)
+{
+    const uint32_t s = item >> 3, c = item & 7u;
+    const uint32_t f4 = s * 16 + c * 2;                      // first of the two float4 holding the 8 floats
+    const float4 a = f4 < stride4 ? row[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = f4 + 1 < stride4 ? row[f4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint4 hi, mid;
+    split8(x, hi, mid);
+    prow[s * 16 + c] = hi;
+    prow[s * 16 + 8 + c] = mid;
+    return (mid.x | mid.y | mid.z | mid.w) != 0;
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float4* rows, uint32_t n_rows, uint32_t stride4, uint4* scr,
+                                                           uint32_t pstride4, uint32_t* any_mid)
+{
+    const uint32_t items_per_row = pstride4 / 2;             // (stage, chunk) pairs
+    const uint64_t total = (uint64_t) n_rows * items_per_row;
+    bool any = false;
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t) gridDim.x * 256) {
+        const uint32_t r = (uint32_t) (i / items_per_row), item = (uint32_t) (i % items_per_row);
+        any |= split_row_item(rows + (size_t) r * stride4, stride4, scr + (size_t) r * pstride4, item);
+    }
+    if (__ballot(any) != 0 && (threadIdx.x & 63) == 0) atomicOr(any_mid, 1u);
+}
+
+hipError_t launch_split_planes(const float4* rows, uint32_t n_rows, uint32_t stride4, int dim, uint4* scr, uint32_t pstride4,
+                               uint32_t* any_mid, hipStream_t s)
+{
+    (void) dim;
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t total = (uint64_t) n_rows * (pstride4 / 2);
+    uint32_t blocks = (uint32_t) std::min<uint64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, rows, n_rows, stride4, scr, pstride4, any_mid);
+    return hipGetLastError();
+}
+
 // Per-batch staging, see StageParams.  Workgroups [0, nq): one query each; the rest copy the descriptor block.
 __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
 {
@@ -482,6 +541,9 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
         p.tau[s] = KEY_EMPTY;
     }
     __syncthreads();
+    if (p.q_scr)                                             // K2w: the query's bf16 hi / mid planes
+        for (uint32_t item = (uint32_t) tid; item < p.pstride4 / 2; item += 256)
+            (void) split_row_item(reinterpret_cast<const float4*>(dst), p.qfloats / 4, p.q_scr + (size_t) s * p.pstride4, item);
     if (tid < 64) {                                          // the arithmetic of row_norms_kernel, one wave per row
         const float4* row = reinterpret_cast<const float4*>(dst);
         float acc = 0.0f;
@@ -717,7 +779,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
             } else {
                 const float a_last = mono_to_float((uint32_t) (bound >> 32));
                 const float d_k = mono_to_float((uint32_t) (keys[p.k - 1] >> 32));
-                const float g = (float) (p.dim + 8) * 5.9604645e-8f;       // (d + 8) * 2^-24
+                const float g = p.err_g;                                   // relative error of the screening dot product
                 const float nxm = *p.norm2_max;
                 float err;
                 if (p.metric == M_L2) err = 2.0f * g * (nxm + qn) + g * fabsf(a_last);

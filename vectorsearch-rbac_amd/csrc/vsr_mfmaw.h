@@ -33,8 +33,12 @@ constexpr int MW_WAVES = 4;
 constexpr int MW_S = 16;                   // float4 chunks per stage (64 floats)
 constexpr int MW_ROWS = 64;                // rows per workgroup tile
 
+#ifndef VSR_MW_OCC
+#define VSR_MW_OCC 2                       // workgroups per CU the register allocation aims at (one query group per wave)
+#endif
+
 template <int METRIC, int NSTR, bool SAMPLE, int NGW>
-__global__ __launch_bounds__(MW_THREADS, 2) void mfma_wide_kernel(const ScanParams p)
+__global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2) void mfma_wide_kernel(const ScanParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -57,13 +61,13 @@ __global__ __launch_bounds__(MW_THREADS, 2) void mfma_wide_kernel(const ScanPara
     const ScanGroup grp = p.groups[lo];
     const uint32_t local_block = p.block_map ? mapped_block : blockIdx.x - grp.block_begin;
 
-    const uint32_t stride4 = p.stride4, cap = p.cap, keep = p.k;
+    const uint32_t pstride4 = p.pstride4, cap = p.cap, keep = p.k;
     const uint32_t q_count = grp.q_count;
     constexpr int NQ = MF_NQ * MW_WAVES * NGW;                                 // query slots of a pass (64 or 128)
 
     // LDS: [stage buffers | row index ring | |row|^2 ring | top-k control | |q|^2 | vote flags]
     const uint32_t stage_bytes = mfmaw_stage_bytes(cap);
-    float4*   stage = reinterpret_cast<float4*>(smem);                          // [2][64 * MW_S]
+    uint4*    stage = reinterpret_cast<uint4*>(smem);                           // [2][64 * MW_S]
     unsigned char* after = smem + stage_bytes;
     int32_t*  rowidx = reinterpret_cast<int32_t*>(after);                       // [4][64]
     float*    rownorm = reinterpret_cast<float*>(after + 4 * 64 * 4);           // [4][64]
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(MW_THREADS, 2) void mfma_wide_kernel(const ScanPara
     const int li = lane & 15;
     const int kq = lane >> 4;
     const int jq = li;
-    float4 bq[NGW][NSTR][4];
+    bf16x8 bh[NGW][NSTR][2], bm[NGW][NSTR][2];                                  // B fragments: hi / mid, 2 K-blocks of 32 per stage
     float my_qn[NGW];
     uint32_t my_qi[NGW];
 #pragma unroll
@@ -102,13 +106,13 @@ __global__ __launch_bounds__(MW_THREADS, 2) void mfma_wide_kernel(const ScanPara
         my_qi[g] = qi < (uint32_t) NQ ? qi : 0u;
         const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];   // pad columns repeat query 0
         my_qn[g] = p.q_norm2[slot];
-        const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
+        const uint4* qsrc = p.q_scr + (size_t) slot * pstride4;                    // planes are zero padded to whole stages
 #pragma unroll
         for (int s = 0; s < NSTR; ++s)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t idx = (uint32_t) (s * MW_S + 4 * t + kq);
-                bq[g][s][t] = idx < stride4 ? qsrc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int blk = 0; blk < 2; ++blk) {
+                bh[g][s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * MW_S + blk * 4 + kq]);
+                bm[g][s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * MW_S + 8 + blk * 4 + kq]);
             }
     }
 
@@ -177,21 +181,21 @@ __global__ __launch_bounds__(MW_THREADS, 2) void mfma_wide_kernel(const ScanPara
 
     // ---- staging: thread -> (row slot u * 16 + lrow, chunk lchunk) of every stage ----
     const int lrow = tid >> 4, lchunk = tid & 15;
-    f32x4 X[NSTR][4];
+    uint4 X[NSTR][4];
     const uint32_t last_row = p.n_rows - 1u;
     auto issue = [&](auto sc, uint32_t it_) {                      // loads of tile it_, stage S into X[S] (no waits)
         // An invalid slot (masked row, ragged tile) loads row 0 and its products are discarded by the epilogue's row
-        // test; the padding chunks of a ragged last stage load chunk 0 and meet the zero padding of the B fragments
-        // (finite x 0: the runtime keeps corpora with NaN / Inf elements off the screening kernels).
+        // test (the runtime keeps corpora with NaN / Inf elements off the screening kernels).  Plane rows are zero
+        // padded to whole stages, so every chunk index is in range.
         constexpr int S = decltype(sc)::value;
         const uint32_t chunk = (uint32_t) (S * MW_S + lchunk);
-        const uint32_t cchunk = chunk < stride4 ? chunk : 0u;
         const int32_t* ridx = rowidx + (it_ & 3u) * 64;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int32_t r = ridx[u * 16 + lrow];
             const uint32_t rc = (uint32_t) (r < 0 ? 0 : r);
-            X[S][u] = *reinterpret_cast<const f32x4*>(p.rows + (size_t) (rc < last_row ? rc : last_row) * stride4 + cchunk);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(p.scr + (size_t) (rc < last_row ? rc : last_row) * pstride4 + chunk);
+            X[S][u] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
     auto issue_all = [&](uint32_t it_) {
@@ -214,11 +218,11 @@ __global__ __launch_bounds__(MW_THREADS, 2) void mfma_wide_kernel(const ScanPara
 
             auto do_stage = [&](auto sc) {
                 constexpr int S = decltype(sc)::value;
-                float4* img = stage + (size_t) buf * (MW_ROWS * MW_S);
+                uint4* img = stage + (size_t) buf * (MW_ROWS * MW_S);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int slot = u * 16 + lrow;
-                    img[slot * MW_S + (lchunk ^ (slot & 15))] = make_float4(X[S][u][0], X[S][u][1], X[S][u][2], X[S][u][3]);
+                    img[slot * MW_S + (lchunk ^ (slot & 15))] = X[S][u];
                 }
                 if (S == 0 && wave == 0) {                         // row mapping, one step per tile (see above)
                     finish_rows(it + 1, pend_row, pend_bw, pend_nrm);
@@ -228,22 +232,24 @@ __global__ __launch_bounds__(MW_THREADS, 2) void mfma_wide_kernel(const ScanPara
                 __syncthreads();
                 if (it + 1 < n_it) issue(sc, it + 1);              // in flight under the MFMAs of a whole tile
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float4 a[NS];
+                for (int blk = 0; blk < 2; ++blk) {                // two K-blocks of 32 per stage
+                    bf16x8 ah[NS], am[NS];
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) a[i] = img[((int) sub0 * 16 + i * 16 + li) * MW_S + ((4 * t + kq) ^ li)];
+                    for (int i = 0; i < NS; ++i) {
+                        const int row = (int) sub0 * 16 + i * 16 + li;
+                        ah[i] = __builtin_bit_cast(bf16x8, img[row * MW_S + ((blk * 4 + kq) ^ li)]);
+                        am[i] = __builtin_bit_cast(bf16x8, img[row * MW_S + ((8 + blk * 4 + kq) ^ li)]);
+                    }
 #pragma unroll
                     for (int g = 0; g < NGW; ++g) {
                         if (!gact[g]) continue;                    // wave-uniform
-                        const float4 b = bq[g][S][t];
+                        // x q ~ xh qh + xh qm + xm qh  (the dropped xm qm and the split residues are inside plane_err_g)
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[g][i], 0, 0, 0);
+                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[g][S][blk], acc[g][i], 0, 0, 0);
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[g][i], 0, 0, 0);
+                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm[g][S][blk], acc[g][i], 0, 0, 0);
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[g][i], 0, 0, 0);
-#pragma unroll
-                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[g][i], 0, 0, 0);
+                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh[g][S][blk], acc[g][i], 0, 0, 0);
                     }
                 }
                 buf ^= 1;
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(MW_THREADS, 2) void mfma_wide_kernel(const ScanPara
 template <int METRIC>
 hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
 {
-    const uint32_t nstage = (p.stride4 + MW_S - 1) / MW_S;
+    const uint32_t nstage = p.pstride4 / MW_S;
     const int ngw = p.qmax > (uint32_t) (MF_NQ * MW_WAVES) ? 2 : 1;
     const size_t lds = mfmaw_lds_bytes(p.cap, ngw);
     auto launch = [&](auto kern) -> hipError_t {

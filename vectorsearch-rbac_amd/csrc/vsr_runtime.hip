@@ -202,6 +202,9 @@ struct vsr_corpus {
     KernelShape shape{};
     float4*     d_rows = nullptr;
     float*      d_norm2 = nullptr;
+    uint4*      d_scr = nullptr;         // K2w screening planes (bf16 hi / mid split of the rows), nullptr: not built
+    uint32_t    pstride4 = 0;            // 16-byte chunks per plane row
+    bool        scr_has_mid = true;      // false: every element is exactly a bf16 value (e.g. SIFT's 0..255 integers)
     float*      d_norm2_max = nullptr;   // max |row|^2 (error bound of K2 screening); +Inf if any |row|^2 is not finite
     bool        k2_safe = true;          // false: some |row|^2 is Inf / NaN (non-finite or huge elements) -> exact kernels only
     int64_t*    d_block = nullptr;
@@ -424,7 +427,7 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
 vsr_corpus::~vsr_corpus()
 {
     drop_cached_filters(this);
-    void* ptrs[] = {d_rows, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
+    void* ptrs[] = {d_rows, d_scr, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
     for (void* p : ptrs)
         if (p) (void) hipFree(p);
 }
@@ -523,6 +526,18 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
         float nmax = 0.0f;
         HIPCHK(hipMemcpy(&nmax, c->d_norm2_max, sizeof(float), hipMemcpyDeviceToHost));
         c->k2_safe = std::isfinite(nmax);
+        // K2w multiplies bf16 hi / mid planes of the rows on the matrix cores (16x the fp32 MFMA rate); the planes are a
+        // second, equally large image of the corpus, built once here (288 GB of HBM: the SIFT10M planes are 5 GB)
+        if (c->k2_safe && mfmaw_supported(c->stride4) && !getenv("VSR_NO_PLANES")) {
+            c->pstride4 = plane_stride4(dim);
+            HIPCHK(hipMalloc(&c->d_scr, alloc_rows * (size_t) c->pstride4 * 16 + 1024));
+            uint32_t* d_any = reinterpret_cast<uint32_t*>(c->d_norm2_max) + 8;      // spare word of the 64-byte block
+            HIPCHK(launch_split_planes(c->d_rows, (uint32_t) n, c->stride4, dim, c->d_scr, c->pstride4, d_any, ctx->stream));
+            uint32_t any = 1;
+            HIPCHK(hipMemcpyAsync(&any, d_any, sizeof any, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            c->scr_has_mid = any != 0;
+        }
     }
     *out = c.release();
     return VSR_OK;
@@ -1031,7 +1046,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     const uint32_t keep = (uint32_t) std::max(2 * k, 32);
     const bool k2_any = allow_screening && ctx->screening && c->k2_safe && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
                         ctx->max_qb >= 16;
-    const bool k2w_ok = k2_any && mfmaw_supported(c->stride4) && mfmaw_cap_for_k(keep) <= 8192 && !ctx->no_wide;
+    const bool k2w_ok = k2_any && c->d_scr && mfmaw_cap_for_k(keep) <= 8192 && !ctx->no_wide;
     const bool k2_ok = k2w_ok || (k2_any && mfma_cap_for_k(keep) <= 8192 && mfma_lds_bytes(c->stride4) <= 150 * 1024);
     int qmax;
     if (k2w_ok) qmax = ctx->max_qb_set ? std::min(ctx->max_qb, mfmaw_qmax(c->stride4)) : mfmaw_qmax(c->stride4);
@@ -1313,7 +1328,8 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     // one staging block: [queries | q_norm2 | scan groups | sample groups | pass query slots | K5 items | list ids]
     const size_t off_q = 0;
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
-    const size_t off_g = align_up(off_qn + (size_t) nq * sizeof(float), 256);
+    const size_t off_qp = align_up(off_qn + (size_t) nq * sizeof(float), 256);       // K2w: query planes (device only)
+    const size_t off_g = align_up(off_qp + (plan.k2w ? (size_t) nq * c->pstride4 * 16 : 0), 256);
     const size_t off_gs = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
     const size_t off_qs = align_up(off_gs + plan.groups_s.size() * sizeof(ScanGroup), 256);
     const size_t off_s1 = align_up(off_qs + plan.q_slots.size() * sizeof(uint32_t), 256);
@@ -1375,6 +1391,8 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         st.qfloats = (uint32_t) qfloats;
         st.nq = (uint32_t) nq;
         st.q_norm2 = reinterpret_cast<float*>(ds + off_qn);
+        st.q_scr = plan.k2w ? reinterpret_cast<uint4*>(ds + off_qp) : nullptr;
+        st.pstride4 = c->pstride4;
         st.flags = ctx->d_flags.as<int32_t>();
         st.tau = ctx->d_tau.as<uint64_t>();
         HIPCHK(launch_stage(st, ctx->stream));
@@ -1389,6 +1407,9 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     sp.stride4 = c->stride4;
     sp.queries = reinterpret_cast<const float*>(ds + off_q);
     sp.q_norm2 = reinterpret_cast<const float*>(ds + off_qn);
+    sp.scr = c->d_scr;
+    sp.q_scr = reinterpret_cast<const uint4*>(ds + off_qp);
+    sp.pstride4 = c->pstride4;
     sp.partial = ctx->d_partial.as<uint64_t>();
     sp.kp = kp;
     sp.k = kp;
@@ -1554,6 +1575,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         rr.out_dist = d_dist;
         rr.out_keys = d_keys;
         rr.out_count = d_cnt;
+        rr.err_g = plan.k2w ? plane_err_g(c->dim) : (float) (c->dim + 8) * 5.9604645e-8f;      // K2: (d + 8) * 2^-24
         rr.seeded = seed ? 1 : 0;
         rr.tau_init = seed ? ctx->d_tau.as<uint64_t>() : nullptr;
         rr.out_flags = ctx->d_flags.as<int32_t>();
