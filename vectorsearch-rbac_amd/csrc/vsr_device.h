@@ -9,6 +9,27 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;   // native vector: loa
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16; // A / B fragment of v_mfma_f32_16x16x32_bf16
 
+// Explicit address spaces.  A pointer that comes out of a struct in memory (ScanGroup::tiles / bitmap) or an access the
+// compiler must not cache (volatile) is "generic" to hipcc and becomes a FLAT instruction, which counts on both the
+// vector-memory and the LDS counter and has to be waited for with s_waitcnt vmcnt(0) lgkmcnt(0): one such load in a tile
+// loop drains every row load that was prefetched for the next tiles.  as_global / lds_peek keep those accesses on
+// global_load (counted vmcnt) and ds_read (lgkmcnt only).
+#ifdef __HIPCC__
+template <class T> using gptr = const __attribute__((address_space(1))) T*;
+template <class T> __device__ __forceinline__ gptr<T> as_global(const T* p) { return (gptr<T>) p; }
+// LDS word that other waves update (running threshold, candidate count, vote flag): re-read it every time
+template <class T> __device__ __forceinline__ T lds_peek(const T* p)
+{
+    return *(const volatile __attribute__((address_space(3))) T*) p;
+}
+// (start, rows) tile descriptor through a global-address-space pointer, as one 8-byte load
+__device__ __forceinline__ uint2 load_tile(gptr<uint2> tiles, uint32_t t)
+{
+    const uint64_t v = ((gptr<uint64_t>) tiles)[t];
+    return make_uint2((uint32_t) v, (uint32_t) (v >> 32));
+}
+#endif
+
 constexpr uint64_t KEY_EMPTY = ~0ull;     // sorts after every real key (NaN keys included)
 constexpr int      SCAN_THREADS = 512;    // 8 waves per workgroup
 constexpr int      SCAN_WAVES = SCAN_THREADS / 64;
@@ -58,7 +79,9 @@ struct ScanParams {
     // K2w screening planes (bf16 hi / mid split of every element, vsr_planes.h layout): corpus rows and query slots
     const uint4*     scr;          // [n_rows][pstride4] 16-byte chunks
     const uint4*     q_scr;        // [n_slots][pstride4]
-    uint32_t         pstride4;     // 16-byte chunks per plane row = 16 * ceil(dim / 64)
+    uint32_t         pstride4;     // 16-byte chunks per corpus plane row (plane_stride4)
+    uint32_t         plane_ho;     // 1: hi-only corpus planes (every element exactly a bf16 value), 128 floats per stage
+    const uint64_t*  ones;         // one all-ones 64-bit word (the "bitmap" of passes without a permission bitmap)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
 };
 
@@ -189,19 +212,22 @@ __host__ __device__ inline uint32_t mfmaw_stage_bytes(uint32_t cap)
     const uint32_t b = cap * 8u;
     return b > 32768u ? b : 32768u;                     // two 64-row x 64-float stage buffers, or the sort buffer
 }
-inline size_t mfmaw_lds_bytes(uint32_t cap, int ngw)
+inline size_t mfmaw_lds_bytes(uint32_t cap)
 {
-    return (size_t) mfmaw_stage_bytes(cap) + 4 * 64 * 8 + (size_t) (64 * ngw) * 20 + 32;
+    return (size_t) mfmaw_stage_bytes(cap) + 8 * 64 * 8 + (size_t) 64 * 16 + 32;     // + row-mapping ring, top-k control
 }
 inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 48; }   // d = 61 .. 192; longer rows: K2
-inline int  mfmaw_qmax(uint32_t stride4) { return stride4 <= 32 ? 128 : 64; }
+inline int  mfmaw_qmax(uint32_t stride4) { (void) stride4; return 64; }
 hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
 // Screening planes: element x = hi + mid + e with hi = bf16(x), mid = bf16(x - hi) (|e| <= 2^-18 |x|).  A plane row holds,
 // for every 64-float stage s, 8 chunks of 8 hi values followed by 8 chunks of 8 mid values (16 bytes each, zero padded):
 // the same 256 bytes per row and stage as the fp32 image, but ready for v_mfma_f32_16x16x32_bf16 (16x the fp32 rate).
-inline uint32_t plane_stride4(int dim) { return 16u * (uint32_t) ((dim + 63) / 64); }
-hipError_t launch_split_planes(const float4* rows, uint32_t n_rows, uint32_t stride4, int dim, uint4* scr, uint32_t pstride4,
-                               uint32_t* any_mid, hipStream_t s);
+// Hi-only layout (ho, every element exactly a bf16 value): 16 hi chunks per 128-float stage, half the bytes.  Query
+// planes always carry hi and mid: [8 hi | 8 mid] per 64-float stage, or (ho) [16 hi | 16 mid] per 128-float stage.
+inline uint32_t plane_stride4(int dim, bool ho) { return 16u * (uint32_t) (ho ? (dim + 127) / 128 : (dim + 63) / 64); }
+hipError_t launch_check_bf16_exact(const float4* rows, uint32_t n_rows, uint32_t stride4, uint32_t* any_inexact, hipStream_t s);
+hipError_t launch_split_planes(const float4* rows, uint32_t n_rows, uint32_t stride4, uint4* scr, uint32_t pstride4, bool ho,
+                               hipStream_t s);
 // relative error bound of the plane product  xh*qh + xh*qm + xm*qh  accumulated in fp32 over `dim` elements
 inline float plane_err_g(int dim) { return 3.0f * 3.8146973e-6f + (float) (3 * dim + 8) * 5.9604645e-8f; }
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
@@ -219,8 +245,10 @@ struct StageParams {
     float*       q_dst;            // nq x qfloats, zero padded
     uint32_t     dim, qfloats, nq;
     float*       q_norm2;          // [nq]
-    uint4*       q_scr;            // [nq][pstride4] bf16 hi / mid planes of the padded queries (nullptr: not needed)
-    uint32_t     pstride4;
+    uint4*       q_scr;            // [nq][q plane stride] bf16 hi / mid planes of the padded queries (nullptr: not needed)
+    uint32_t     pstride4;         // corpus plane stride
+    uint32_t     plane_ho;         // corpus layout; query planes: pstride4 chunks (hi + mid per 64-float stage) or, hi-only
+                                   // corpus, 2 * pstride4 chunks (16 hi + 16 mid chunks per 128-float stage)
     int32_t*     flags;            // [nq] <- 0
     uint64_t*    tau;              // [nq] <- KEY_EMPTY (no seed)
 };

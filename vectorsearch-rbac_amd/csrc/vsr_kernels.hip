@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NT) void select_kernel(const SelectParams p)
     for (uint64_t base = 0; base < total; base += NT) {
         const uint64_t key = next;
         next = fetch(base + NT + tid);
-        const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl->tau);
+        const uint64_t tau = lds_peek(&ctrl->tau);
         topk_append(keys, ctrl, key < tau, key);            // KEY_EMPTY never passes (tau <= KEY_EMPTY)
         if (base + NT < total) {
             __syncthreads();                                 // every append of this round is counted
@@ -484,42 +484,67 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& mi
     mid = make_uint4(m[0] | (uint32_t) m[1] << 16, m[2] | (uint32_t) m[3] << 16, m[4] | (uint32_t) m[5] << 16, m[6] | (uint32_t) m[7] << 16);
 }
 
-// planes of one padded fp32 row (stride4 float4, zeros past dim): item = (stage, chunk c < 8) covers floats 64 s + 8 c ..
-__device__ __forceinline__ bool split_row_item(const float4* row, uint32_t stride4, uint4* prow, uint32_t item)
+// planes of one padded fp32 row (stride4 float4, zeros past dim).  Two layouts (vsr_device.h, plane_stride4):
+//   hi + mid:  item = (64-float stage s, chunk c < 8)   -> hi at prow[16 s + c], mid at prow[16 s + 8 + c]
+//   hi only :  item = (128-float stage s, chunk c < 16) -> hi at prow[hs s + c] and, for query rows (mid_off = 16,
+//              hs = 32), mid at prow[hs s + 16 + c]; corpus rows (mid_off = 0, hs = 16) store no mid at all
+__device__ __forceinline__ void split_row_item(const float4* row, uint32_t stride4, uint4* prow, uint32_t item, bool ho,
+                                               uint32_t ho_stage_chunks, uint32_t ho_mid_off)
 {
-    const uint32_t s = item >> 3, c = item & 7u;
-    const uint32_t f4 = s * 16 + c * 2;                      // first of the two float4 holding the 8 floats
+    const uint32_t s = ho ? item >> 4 : item >> 3, c = ho ? item & 15u : item & 7u;
+    const uint32_t f4 = (ho ? s * 32 : s * 16) + c * 2;      // first of the two float4 holding the 8 floats
     const float4 a = f4 < stride4 ? row[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 b = f4 + 1 < stride4 ? row[f4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint4 hi, mid;
     split8(x, hi, mid);
-    prow[s * 16 + c] = hi;
-    prow[s * 16 + 8 + c] = mid;
-    return (mid.x | mid.y | mid.z | mid.w) != 0;
+    if (ho) {
+        prow[s * ho_stage_chunks + c] = hi;
+        if (ho_mid_off) prow[s * ho_stage_chunks + ho_mid_off + c] = mid;
+    } else {
+        prow[s * 16 + c] = hi;
+        prow[s * 16 + 8 + c] = mid;
+    }
 }
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const float4* rows, uint32_t n_rows, uint32_t stride4, uint4* scr,
-                                                           uint32_t pstride4, uint32_t* any_mid)
+                                                           uint32_t pstride4, int ho)
 {
-    const uint32_t items_per_row = pstride4 / 2;             // (stage, chunk) pairs
+    const uint32_t items_per_row = ho ? pstride4 : pstride4 / 2;
     const uint64_t total = (uint64_t) n_rows * items_per_row;
-    bool any = false;
     for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t) gridDim.x * 256) {
         const uint32_t r = (uint32_t) (i / items_per_row), item = (uint32_t) (i % items_per_row);
-        any |= split_row_item(rows + (size_t) r * stride4, stride4, scr + (size_t) r * pstride4, item);
+        split_row_item(rows + (size_t) r * stride4, stride4, scr + (size_t) r * pstride4, item, ho != 0, 16u, 0u);
     }
-    if (__ballot(any) != 0 && (threadIdx.x & 63) == 0) atomicOr(any_mid, 1u);
 }
 
-hipError_t launch_split_planes(const float4* rows, uint32_t n_rows, uint32_t stride4, int dim, uint4* scr, uint32_t pstride4,
-                               uint32_t* any_mid, hipStream_t s)
+hipError_t launch_split_planes(const float4* rows, uint32_t n_rows, uint32_t stride4, uint4* scr, uint32_t pstride4, bool ho,
+                               hipStream_t s)
 {
-    (void) dim;
     if (n_rows == 0) return hipSuccess;
-    const uint64_t total = (uint64_t) n_rows * (pstride4 / 2);
+    const uint64_t total = (uint64_t) n_rows * (ho ? pstride4 : pstride4 / 2);
     uint32_t blocks = (uint32_t) std::min<uint64_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, rows, n_rows, stride4, scr, pstride4, any_mid);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, rows, n_rows, stride4, scr, pstride4, ho ? 1 : 0);
+    return hipGetLastError();
+}
+
+// does any element differ from its bf16 rounding?  (0 / -0 count as exact)
+__global__ __launch_bounds__(256) void check_bf16_exact_kernel(const float4* rows, uint64_t n4, uint32_t* any_inexact)
+{
+    bool bad = false;
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t) gridDim.x * 256) {
+        const float4 v = rows[i];
+        bad |= v.x != (float) (__bf16) v.x || v.y != (float) (__bf16) v.y || v.z != (float) (__bf16) v.z || v.w != (float) (__bf16) v.w;
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(any_inexact, 1u);
+}
+
+hipError_t launch_check_bf16_exact(const float4* rows, uint32_t n_rows, uint32_t stride4, uint32_t* any_inexact, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t n4 = (uint64_t) n_rows * stride4;
+    uint32_t blocks = (uint32_t) std::min<uint64_t>((n4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(check_bf16_exact_kernel, dim3(blocks), dim3(256), 0, s, rows, n4, any_inexact);
     return hipGetLastError();
 }
 
@@ -541,9 +566,13 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
         p.tau[s] = KEY_EMPTY;
     }
     __syncthreads();
-    if (p.q_scr)                                             // K2w: the query's bf16 hi / mid planes
-        for (uint32_t item = (uint32_t) tid; item < p.pstride4 / 2; item += 256)
-            (void) split_row_item(reinterpret_cast<const float4*>(dst), p.qfloats / 4, p.q_scr + (size_t) s * p.pstride4, item);
+    if (p.q_scr) {                                           // K2w: the query's bf16 hi / mid planes
+        const uint32_t qstride = p.plane_ho ? 2 * p.pstride4 : p.pstride4;
+        const uint32_t items = p.plane_ho ? p.pstride4 : p.pstride4 / 2;
+        for (uint32_t item = (uint32_t) tid; item < items; item += 256)
+            split_row_item(reinterpret_cast<const float4*>(dst), p.qfloats / 4, p.q_scr + (size_t) s * qstride, item,
+                           p.plane_ho != 0, 32u, 16u);
+    }
     if (tid < 64) {                                          // the arithmetic of row_norms_kernel, one wave per row
         const float4* row = reinterpret_cast<const float4*>(dst);
         float acc = 0.0f;

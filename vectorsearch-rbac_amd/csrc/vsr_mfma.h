@@ -68,6 +68,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     }
     const ScanGroup grp = p.groups[lo];
     const uint32_t local_block = p.block_map ? mapped_block : blockIdx.x - grp.block_begin;
+    const auto g_tiles = as_global(grp.tiles);                                 // global_load, not flat (vsr_device.h)
+    const auto g_bitmap = as_global(grp.bitmap);
 
     const uint32_t stride4 = p.stride4, cap = p.cap, keep = p.k;
     const uint32_t nstage = (stride4 + MF_S - 1) / MF_S;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
             atomicOr(p.err, 4u);
             return make_uint2(0u, 0u);
         }
-        if (grp.tiles) return grp.tiles[t];
+        if (g_tiles) return load_tile(g_tiles, t);
         const uint32_t start = t * rw;
         return make_uint2(start, p.n_rows - start < rw ? p.n_rows - start : rw);
     };
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
             atomicOr(p.err, 1u);
             return -1;
         }
-        if (grp.bitmap && !((grp.bitmap[row >> 6] >> (row & 63)) & 1ull)) return -1;
+        if (g_bitmap && !((g_bitmap[row >> 6] >> (row & 63)) & 1ull)) return -1;
         return (int32_t) row;
     };
     float4 x[MF_S];
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const uint32_t qi = (uint32_t) (g * MF_NQ + jq);
-                const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[qi].tau);
+                const uint64_t tau = lds_peek(&ctrl[qi].tau);
                 const bool qok = qi < q_count;
                 // screening test in float: a value is a candidate unless it is greater than the threshold's distance
                 // (NaN values and an open / NaN threshold pass).  That admits a superset of `key < tau` (ties of the
@@ -333,11 +335,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
         if (it + 1 < iters && (it + 1) % K2_VOTE_EVERY == 0) {
             bool need = false;
             for (uint32_t q = 0; q < q_count; ++q)
-                need |= *reinterpret_cast<volatile uint32_t*>(&ctrl[q].count) > trigger;
+                need |= lds_peek(&ctrl[q].count) > trigger;
             const uint32_t slot = round % 3;
             if (need && lane == 0) atomicOr(&flags[slot], 1u);
             __syncthreads();
-            const bool any = *reinterpret_cast<volatile uint32_t*>(&flags[slot]) != 0;
+            const bool any = lds_peek(&flags[slot]) != 0;
             if (tid == 0) flags[(round + 2) % 3] = 0;
             ++round;
             if (any) {

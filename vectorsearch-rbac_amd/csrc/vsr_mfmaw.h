@@ -3,22 +3,29 @@
 // A permission class (or any filter part) that many queries see is a GEMM: dot[row][query], rows = the class's rows,
 // queries = everyone whose role sees the class, K = d.  K2 (vsr_mfma.h) gave every WAVE its own row tile and 16 (32)
 // queries, so a class seen by 330 queries was streamed 21 times.  K2w stages a 64-row tile ONCE per WORKGROUP in LDS
-// and multiplies it against up to 64 * NGW queries whose B fragments live in the registers of the four waves:
+// and multiplies it against up to 64 queries whose B fragments live in the registers of the four waves:
 //
-//   wave w owns query group(s) {w, w + 4} (16 queries each) and reads the whole shared tile        (>= 3 groups)
+//   >= 3 query groups (16 queries each): wave w owns group w and reads the whole shared tile
 //   2 groups: two waves per group, two 16-row sub-tiles each; 1 group: four waves, one sub-tile each (row split),
 //
-// so narrow passes (a leaf class seen by 10 queries) still use all four waves and stay HBM-bound, while fat passes run
-// at the matrix pipe's pace with the rows read once per <= 128 queries.
+// so narrow passes (a leaf class seen by 10 queries) still use all four waves.
 //
-// Pipeline (register staging, MI355X guide T14 / G15): a thread owns 4 float4 of every 64-row x 64-float stage; the
-// loads of tile i+1 are issued as soon as the registers of tile i have been written to LDS (a whole tile = NSTR stages
-// = 32 KB per workgroup at d = 128 stays in flight under the MFMAs of tile i), two LDS stage buffers, one barrier per
-// stage.  The row mapping of a tile (tile descriptor -> row -> permission bit, |row|^2) is resolved by wave 0 three
-// tiles ahead, one dependent load per iteration, so no wave ever waits for it.
+// Arithmetic: the tile is not the fp32 rows but their SCREENING PLANES (vsr_device.h, plane_stride4): every element
+// x = hi + mid (+ e, |e| <= 2^-18 |x|) as two bf16 values, so the dot products run on v_mfma_f32_16x16x32_bf16 at 16x
+// the fp32 MFMA rate:  x q ~ xh qh + xh qm + xm qh  (fp32 accumulation).  The result only SCREENS: it decides which
+// kp = 2k candidates per query survive; K5r recomputes the exact vector.c arithmetic for them from the fp32 rows and
+// flags a query whose kept / dropped gap is inside the screening's error bound (plane_err_g).  A corpus whose elements
+// are all exactly bf16 values (SIFT's 0..255 integers) has no mid plane at all (HO = "hi only"): half the bytes per
+// row, and the screening is then exact for such queries.  With the dot products this cheap every pass is bound by the
+// row stream, so what matters is bytes in flight:
 //
-// Arithmetic, screening keys, candidate buffers, compaction votes and the final per-query radix selection are those of
-// K2 (vsr_mfma.h); K5r re-ranks the survivors exactly.
+// Pipeline (register staging, MI355X guide T14 / G15): a thread owns 4 chunks (16 bytes each) of every 64-row stage;
+// the loads of tile i + DEPTH are issued as soon as the registers of tile i have been written to LDS, so DEPTH whole
+// tiles per workgroup are in flight under the work of tile i; two LDS stage buffers, one barrier per stage.  The row
+// mapping of a tile (tile descriptor -> row -> permission bit, |row|^2) is resolved by wave 0 up to 3 * DEPTH tiles
+// ahead, one dependent load per DEPTH tiles, so its latency is covered like that of the row data.
+//
+// Screening keys, candidate buffers, compaction votes and the final per-query radix selection are those of K2.
 #pragma once
 #include <type_traits>
 #include "vsr_device.h"
@@ -30,16 +37,37 @@ namespace vsr {
 
 constexpr int MW_THREADS = 256;
 constexpr int MW_WAVES = 4;
-constexpr int MW_S = 16;                   // float4 chunks per stage (64 floats)
+constexpr int MW_S = 16;                   // 16-byte chunks per row and stage
 constexpr int MW_ROWS = 64;                // rows per workgroup tile
+constexpr int MW_NQ = MF_NQ * MW_WAVES;    // query slots of a pass
+constexpr int MW_RING = 8;                 // row-mapping ring (tiles): >= DEPTH + 2
 
-#ifndef VSR_MW_OCC
-#define VSR_MW_OCC 2                       // workgroups per CU the register allocation aims at (one query group per wave)
+// Tiles in flight per workgroup and workgroups per CU the register allocation aims at, by stages per row: the staging
+// registers of DEPTH tiles (16 * NCH * DEPTH VGPRs) and the B fragments (16 or 32 * NCH) share the budget.
+#ifndef VSR_MW_DEPTH1
+#define VSR_MW_DEPTH1 1
 #endif
+#ifndef VSR_MW_OCC1
+#define VSR_MW_OCC1 3
+#endif
+constexpr int mw_depth(int nch) { return nch == 1 ? VSR_MW_DEPTH1 : nch == 2 ? 2 : 1; }
+constexpr int mw_occ(int nch) { return nch == 1 ? VSR_MW_OCC1 : 2; }
 
-template <int METRIC, int NSTR, bool SAMPLE, int NGW>
-__global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2) void mfma_wide_kernel(const ScanParams p)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases global memory, and since gfx950 counts
+// stores and loads in the one vmcnt queue that costs an s_waitcnt vmcnt(0): every prefetched row load would be drained at
+// every stage.  Inside the tile loop only the LDS image and the LDS rings are handed between waves, so the waves wait for
+// their own LDS operations (lgkmcnt) and meet at a bare s_barrier; the candidate stores to global memory are ordered by a
+// full __syncthreads() before anybody reads them back (compaction, publish).
+__device__ __forceinline__ void lds_barrier()
 {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// NCH: stages per row (16 chunks = 256 bytes each): 64 floats per stage with hi + mid planes, 128 floats hi-only.
+template <int METRIC, int NCH, bool SAMPLE, bool HO, int DEPTH>
+__global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(const ScanParams p)
+{
+    static_assert(DEPTH >= 1 && DEPTH <= 4 && DEPTH + 2 <= MW_RING, "row-mapping ring too short");
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,59 +88,57 @@ __global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2)
     }
     const ScanGroup grp = p.groups[lo];
     const uint32_t local_block = p.block_map ? mapped_block : blockIdx.x - grp.block_begin;
+    const auto g_tiles = as_global(grp.tiles);                                 // global_load, not flat (vsr_device.h)
+    const auto g_bitmap = as_global(grp.bitmap);
+    const auto g_norm2 = as_global(p.norm2);
+    const auto g_ones = as_global(p.ones);
 
     const uint32_t pstride4 = p.pstride4, cap = p.cap, keep = p.k;
     const uint32_t q_count = grp.q_count;
-    constexpr int NQ = MF_NQ * MW_WAVES * NGW;                                 // query slots of a pass (64 or 128)
 
-    // LDS: [stage buffers | row index ring | |row|^2 ring | top-k control | |q|^2 | vote flags]
+    // LDS: [stage buffers | row index ring | |row|^2 ring | top-k control | vote flags]
     const uint32_t stage_bytes = mfmaw_stage_bytes(cap);
     uint4*    stage = reinterpret_cast<uint4*>(smem);                           // [2][64 * MW_S]
     unsigned char* after = smem + stage_bytes;
-    int32_t*  rowidx = reinterpret_cast<int32_t*>(after);                       // [4][64]
-    float*    rownorm = reinterpret_cast<float*>(after + 4 * 64 * 4);           // [4][64]
-    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(after + 4 * 64 * 8);
-    float*    qnl = reinterpret_cast<float*>(ctrl + NQ);
-    uint32_t* flags = reinterpret_cast<uint32_t*>(qnl + NQ);
+    int32_t*  rowidx = reinterpret_cast<int32_t*>(after);                       // [MW_RING][64]
+    float*    rownorm = reinterpret_cast<float*>(after + MW_RING * 64 * 4);     // [MW_RING][64]
+    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(after + MW_RING * 64 * 8);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(ctrl + MW_NQ);
     uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem);
 
-    for (uint32_t qi = tid; qi < (uint32_t) NQ; qi += MW_THREADS) {
+    for (uint32_t qi = tid; qi < (uint32_t) MW_NQ; qi += MW_THREADS) {
         const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         ctrl[qi].count = 0;
-        qnl[qi] = p.q_norm2[slot];
     }
     if (tid < 4) flags[tid] = 0;
 
     // ---- wave roles ----
-    const uint32_t ngt = (q_count + MF_NQ - 1) / MF_NQ;                         // 16-query groups of this pass
+    const uint32_t ngt = (q_count + MF_NQ - 1) / MF_NQ;                         // 16-query groups of this pass (1..4)
     const uint32_t rsplit = ngt == 1 ? 4u : ngt == 2 ? 2u : 1u;                 // waves sharing one group's rows
-    const uint32_t g0 = (uint32_t) wave / rsplit;                               // this wave's (first) query group
+    const uint32_t g0 = (uint32_t) wave / rsplit;                               // this wave's query group
     const uint32_t sub0 = ((uint32_t) wave % rsplit) * (4u / rsplit);           // its first 16-row sub-tile
-    bool gact[NGW];
-#pragma unroll
-    for (int g = 0; g < NGW; ++g) gact[g] = g0 + (uint32_t) g * MW_WAVES < ngt;
+    const bool gact = g0 < ngt;                                                 // wave-uniform
 
-    // MFMA lane roles: A operand lane = (row i, k-quad kq); B operand / result lane = (k-quad kq, query jq)
+    // MFMA lane roles (16x16x32): A lane = (row li, k-octet kq); B / result lane = (k-octet kq | row quad kq, query jq)
     const int li = lane & 15;
     const int kq = lane >> 4;
     const int jq = li;
-    bf16x8 bh[NGW][NSTR][2], bm[NGW][NSTR][2];                                  // B fragments: hi / mid, 2 K-blocks of 32 per stage
-    float my_qn[NGW];
-    uint32_t my_qi[NGW];
+    constexpr int NBLK = HO ? 4 : 2;                                           // K-blocks of 32 per stage
+    bf16x8 bh[NCH][NBLK], bm[NCH][NBLK];                                        // B fragments: hi / mid planes of the query
+    const uint32_t my_qi = g0 * MF_NQ + (uint32_t) jq < (uint32_t) MW_NQ ? g0 * MF_NQ + (uint32_t) jq : 0u;
+    float my_qn;
+    {
+        const uint32_t slot = p.q_slots[grp.q_begin + (my_qi < q_count ? my_qi : 0)];   // pad columns repeat query 0
+        my_qn = p.q_norm2[slot];
+        // query planes: per stage [hi chunks | mid chunks] (8 + 8 of a 64-float stage; 16 + 16 of a 128-float one)
+        const uint4* qsrc = p.q_scr + (size_t) slot * (HO ? 2 * pstride4 : pstride4);
 #pragma unroll
-    for (int g = 0; g < NGW; ++g) {
-        const uint32_t qi = (g0 + (uint32_t) g * MW_WAVES) * MF_NQ + (uint32_t) jq;
-        my_qi[g] = qi < (uint32_t) NQ ? qi : 0u;
-        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];   // pad columns repeat query 0
-        my_qn[g] = p.q_norm2[slot];
-        const uint4* qsrc = p.q_scr + (size_t) slot * pstride4;                    // planes are zero padded to whole stages
+        for (int s = 0; s < NCH; ++s)
 #pragma unroll
-        for (int s = 0; s < NSTR; ++s)
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                bh[g][s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * MW_S + blk * 4 + kq]);
-                bm[g][s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * MW_S + 8 + blk * 4 + kq]);
+            for (int blk = 0; blk < NBLK; ++blk) {
+                bh[s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * (HO ? 32 : 16) + blk * 4 + kq]);
+                bm[s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * (HO ? 32 : 16) + (HO ? 16 : 8) + blk * 4 + kq]);
             }
     }
 
@@ -123,98 +149,117 @@ __global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2)
     const uint32_t n_super = (t1 - t0 + tps - 1) / tps;
     const uint32_t ss = p.sample_stride;                                        // sample pass: every ss-th tile
     const uint32_t n_it = (n_super + ss - 1) / ss;
-    const uint32_t slack = mfmaw_slack();
-    const uint32_t trigger = cap - slack;
+    const uint32_t trigger = cap - mfmaw_slack();
     uint64_t* cand = p.cand + (size_t) (grp.partial_begin + local_block) * cand_pitch(cap);
     const size_t cand_qstride = (size_t) grp.n_blocks * cand_pitch(cap);
 
-    // ---- row mapping pipeline (wave 0, lane = row slot): descriptor at it+3, row + bitmap word + norm at it+2,
-    // written to the LDS ring at it+1, used by the loads issued during tile it and by the epilogue of tile it+1 ----
+    // ---- row mapping pipeline (wave 0, lane = row slot): at tile `it` the descriptor of tile it+3*DEPTH is fetched, the
+    // row / bitmap word / norm of tile it+2*DEPTH are started and those of tile it+DEPTH are written to the LDS ring, where
+    // the loads issued during tile `it` (for tile it+DEPTH) and later that tile's epilogue find them: every dependent load
+    // has the time of DEPTH tiles to arrive, like the row data itself ----
+    // Branch-free on purpose (addresses are clamped, results selected): a load inside a conditional block leaves the
+    // compiler's wait-count bookkeeping with several histories and it falls back to s_waitcnt vmcnt(0), which would
+    // drain the row loads prefetched for the next tiles at every tile.  The planner always hands K2w an explicit tile
+    // list (unfiltered queries use the corpus's identity list) and groups with n_tiles == 0 are never launched.
+    const uint32_t tile_last = grp.n_tiles - 1u;
     auto fetch_desc = [&](uint32_t it_) -> uint2 {                 // (start, nrows) of this lane's list tile, or (0, 0)
-        if (it_ >= n_it) return make_uint2(0u, 0u);
         const uint32_t t = t0 + it_ * ss * tps + (uint32_t) lane / rw;
-        if (t >= t1) return make_uint2(0u, 0u);
-        if (t >= grp.n_tiles) {                                    // cannot happen; never read past the tile list
-            atomicOr(p.err, 4u);
-            return make_uint2(0u, 0u);
-        }
-        if (grp.tiles) return grp.tiles[t];
-        const uint32_t start = t * rw;
-        return make_uint2(start, p.n_rows - start < rw ? p.n_rows - start : rw);
+        const bool ok = it_ < n_it && t < t1;
+        const uint2 d = load_tile(g_tiles, t < tile_last ? t : tile_last);
+        return make_uint2(ok ? d.x : 0u, ok ? d.y : 0u);
     };
-    int32_t  pend_row = -1;                                        // tile it+1: row (before the permission bit)
-    uint64_t pend_bw = ~0ull;                                      //            its bitmap word (in flight)
-    float    pend_nrm = 0.0f;                                      //            its |row|^2 (in flight)
-    uint2    dsc_a = make_uint2(0u, 0u);                           // tile it+2: descriptor (in flight)
+    // tile `it` uses ring slot D = it % DEPTH of every register ring below, so each is indexed at compile time
+    int32_t  pend_row[DEPTH];                                      // tile it+2*DEPTH: row (before the permission bit)
+    uint64_t pend_bw[DEPTH];                                       //                  its bitmap word (in flight)
+    float    pend_nrm[DEPTH];                                      //                  its |row|^2 (in flight)
+    uint2    dsc_a[DEPTH];                                         // tile it+3*DEPTH: descriptor (in flight)
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+        pend_row[j] = -1;
+        pend_bw[j] = ~0ull;
+        pend_nrm[j] = 0.0f;
+        dsc_a[j] = make_uint2(0u, 0u);
+    }
+    bool bad_row = false;                                          // cannot happen; reported once at the end
     auto start_rows = [&](uint2 d, int32_t& row, uint64_t& bw, float& nrm) {
         const uint32_t r = (uint32_t) lane % rw;
-        row = -1;
-        bw = ~0ull;
-        nrm = 0.0f;
-        if (r < d.y) {
-            const uint32_t rr = d.x + r;
-            if (rr >= p.n_rows) {                                  // cannot happen; never read past the corpus
-                atomicOr(p.err, 1u);
-            } else {
-                row = (int32_t) rr;
-                if (grp.bitmap) bw = grp.bitmap[rr >> 6];
-                nrm = p.norm2[rr];
-            }
-        }
+        const uint32_t rr = d.x + r;
+        const bool ok = r < d.y && rr < p.n_rows;
+        bad_row |= r < d.y && rr >= p.n_rows;
+        const uint32_t rc = ok ? rr : 0u;
+        row = ok ? (int32_t) rr : -1;
+        bw = *(g_bitmap ? g_bitmap + (rc >> 6) : g_ones);          // no bitmap: one all-ones word
+        nrm = g_norm2[rc];
     };
+    // Every wave runs the (identical) mapping loads and wave 0 writes the ring: a wave-0-only branch around the loads
+    // would leave the compiler's wait-count bookkeeping with two histories to merge at every tile, and it then waits for
+    // ALL outstanding loads -- the prefetched row data included -- instead of counting.
     auto finish_rows = [&](uint32_t it_, int32_t row, uint64_t bw, float nrm) {
         if (row >= 0 && !((bw >> ((uint32_t) row & 63u)) & 1ull)) row = -1;
-        rowidx[(it_ & 3u) * 64 + lane] = row;
-        rownorm[(it_ & 3u) * 64 + lane] = row >= 0 ? nrm : 0.0f;
+        if (wave == 0) {
+            rowidx[(it_ % MW_RING) * 64 + lane] = row;
+            rownorm[(it_ % MW_RING) * 64 + lane] = row >= 0 ? nrm : 0.0f;
+        }
     };
-    if (wave == 0) {
-        const uint2 d0 = fetch_desc(0), d1 = fetch_desc(1);
-        dsc_a = fetch_desc(2);
-        int32_t r0;
-        uint64_t b0;
-        float n0;
-        start_rows(d0, r0, b0, n0);
-        start_rows(d1, pend_row, pend_bw, pend_nrm);
-        finish_rows(0, r0, b0, n0);
+    {
+        uint2 d[2 * DEPTH];
+#pragma unroll
+        for (int j = 0; j < 2 * DEPTH; ++j) d[j] = fetch_desc((uint32_t) j);
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) dsc_a[j] = fetch_desc((uint32_t) (2 * DEPTH + j));
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            int32_t r0;
+            uint64_t b0;
+            float n0;
+            start_rows(d[j], r0, b0, n0);
+            finish_rows((uint32_t) j, r0, b0, n0);
+            start_rows(d[DEPTH + j], pend_row[j], pend_bw[j], pend_nrm[j]);
+        }
     }
     __syncthreads();
 
     // ---- staging: thread -> (row slot u * 16 + lrow, chunk lchunk) of every stage ----
     const int lrow = tid >> 4, lchunk = tid & 15;
-    uint4 X[NSTR][4];
+    uint4 X[DEPTH][NCH][4];
     const uint32_t last_row = p.n_rows - 1u;
-    auto issue = [&](auto sc, uint32_t it_) {                      // loads of tile it_, stage S into X[S] (no waits)
+    auto issue = [&](auto dc, auto sc, uint32_t it_) {             // loads of tile it_, stage S into ring slot D (no waits)
         // An invalid slot (masked row, ragged tile) loads row 0 and its products are discarded by the epilogue's row
         // test (the runtime keeps corpora with NaN / Inf elements off the screening kernels).  Plane rows are zero
         // padded to whole stages, so every chunk index is in range.
+        constexpr int D = decltype(dc)::value;
         constexpr int S = decltype(sc)::value;
         const uint32_t chunk = (uint32_t) (S * MW_S + lchunk);
-        const int32_t* ridx = rowidx + (it_ & 3u) * 64;
+        const int32_t* ridx = rowidx + (it_ % MW_RING) * 64;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int32_t r = ridx[u * 16 + lrow];
             const uint32_t rc = (uint32_t) (r < 0 ? 0 : r);
             const u32x4 v = *reinterpret_cast<const u32x4*>(p.scr + (size_t) (rc < last_row ? rc : last_row) * pstride4 + chunk);
-            X[S][u] = make_uint4(v[0], v[1], v[2], v[3]);
+            X[D][S][u] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
-    auto issue_all = [&](uint32_t it_) {
-        issue(std::integral_constant<int, 0>{}, it_);
-        if constexpr (NSTR > 1) issue(std::integral_constant<int, 1>{}, it_);
-        if constexpr (NSTR > 2) issue(std::integral_constant<int, 2>{}, it_);
+    auto issue_tile = [&](auto dc, uint32_t it_) {
+        issue(dc, std::integral_constant<int, 0>{}, it_);
+        if constexpr (NCH > 1) issue(dc, std::integral_constant<int, 1>{}, it_);
+        if constexpr (NCH > 2) issue(dc, std::integral_constant<int, 2>{}, it_);
     };
-    if (n_it > 0) issue_all(0);
+    const uint32_t n_pad = (n_it + DEPTH - 1) / DEPTH * DEPTH;
+    issue_tile(std::integral_constant<int, 0>{}, 0);
+    if constexpr (DEPTH > 1) issue_tile(std::integral_constant<int, 1>{}, 1);
+    if constexpr (DEPTH > 2) issue_tile(std::integral_constant<int, 2>{}, 2);
+    if constexpr (DEPTH > 3) issue_tile(std::integral_constant<int, 3>{}, 3);
 
     uint32_t round = 0;
     auto run = [&](auto nsc) {
         constexpr int NS = decltype(nsc)::value;                   // 16-row sub-tiles of this wave (1, 2 or 4)
+        constexpr int NH = NS > 2 ? 2 : NS;                        // sub-tiles whose A fragments are live at a time
         int buf = 0;
-        for (uint32_t it = 0; it < n_it; ++it) {
-            f32x4 acc[NGW][NS];
+        auto tile = [&](auto dc, uint32_t it) {
+            constexpr int D = decltype(dc)::value;
+            f32x4 acc[NS];
 #pragma unroll
-            for (int g = 0; g < NGW; ++g)
-#pragma unroll
-                for (int i = 0; i < NS; ++i) acc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
             auto do_stage = [&](auto sc) {
                 constexpr int S = decltype(sc)::value;
@@ -222,57 +267,57 @@ __global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int slot = u * 16 + lrow;
-                    img[slot * MW_S + (lchunk ^ (slot & 15))] = X[S][u];
+                    img[slot * MW_S + (lchunk ^ (slot & 15))] = X[D][S][u];      // XOR-swizzled image
                 }
-                if (S == 0 && wave == 0) {                         // row mapping, one step per tile (see above)
-                    finish_rows(it + 1, pend_row, pend_bw, pend_nrm);
-                    start_rows(dsc_a, pend_row, pend_bw, pend_nrm);
-                    dsc_a = fetch_desc(it + 3);
+                if constexpr (S == 0) {                            // row mapping, one step per tile (see above)
+                    finish_rows(it + DEPTH, pend_row[D], pend_bw[D], pend_nrm[D]);
+                    start_rows(dsc_a[D], pend_row[D], pend_bw[D], pend_nrm[D]);
+                    dsc_a[D] = fetch_desc(it + 3 * DEPTH);
                 }
-                __syncthreads();
-                if (it + 1 < n_it) issue(sc, it + 1);              // in flight under the MFMAs of a whole tile
+                lds_barrier();
+                issue(dc, sc, it + DEPTH);                         // in flight under the work of DEPTH whole tiles (past the
+                                                                   // last tile: all slots invalid, row 0 from the cache)
+                if (gact) {
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {                // two K-blocks of 32 per stage
-                    bf16x8 ah[NS], am[NS];
+                    for (int h0 = 0; h0 < NS; h0 += NH)
 #pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const int row = (int) sub0 * 16 + i * 16 + li;
-                        ah[i] = __builtin_bit_cast(bf16x8, img[row * MW_S + ((blk * 4 + kq) ^ li)]);
-                        am[i] = __builtin_bit_cast(bf16x8, img[row * MW_S + ((8 + blk * 4 + kq) ^ li)]);
-                    }
+                        for (int blk = 0; blk < NBLK; ++blk) {
+                            bf16x8 ah[NH], am[NH];
 #pragma unroll
-                    for (int g = 0; g < NGW; ++g) {
-                        if (!gact[g]) continue;                    // wave-uniform
-                        // x q ~ xh qh + xh qm + xm qh  (the dropped xm qm and the split residues are inside plane_err_g)
+                            for (int i = 0; i < NH; ++i) {
+                                const int row = ((int) sub0 + h0 + i) * 16 + li;
+                                ah[i] = __builtin_bit_cast(bf16x8, img[row * MW_S + ((blk * 4 + kq) ^ li)]);
+                                if constexpr (!HO) am[i] = __builtin_bit_cast(bf16x8, img[row * MW_S + ((8 + blk * 4 + kq) ^ li)]);
+                            }
+                            // x q ~ xh qh + xh qm + xm qh  (the dropped xm qm and the split residues: plane_err_g)
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[g][S][blk], acc[g][i], 0, 0, 0);
+                            for (int i = 0; i < NH; ++i) acc[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[S][blk], acc[h0 + i], 0, 0, 0);
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm[g][S][blk], acc[g][i], 0, 0, 0);
+                            for (int i = 0; i < NH; ++i) acc[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm[S][blk], acc[h0 + i], 0, 0, 0);
+                            if constexpr (!HO) {
 #pragma unroll
-                        for (int i = 0; i < NS; ++i) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh[g][S][blk], acc[g][i], 0, 0, 0);
-                    }
+                                for (int i = 0; i < NH; ++i) acc[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh[S][blk], acc[h0 + i], 0, 0, 0);
+                            }
+                        }
                 }
                 buf ^= 1;
             };
             do_stage(std::integral_constant<int, 0>{});
-            if constexpr (NSTR > 1) do_stage(std::integral_constant<int, 1>{});
-            if constexpr (NSTR > 2) do_stage(std::integral_constant<int, 2>{});
+            if constexpr (NCH > 1) do_stage(std::integral_constant<int, 1>{});
+            if constexpr (NCH > 2) do_stage(std::integral_constant<int, 2>{});
 
-            // results: acc[g][i][r] = dot(row slot (sub0 + i) * 16 + kq * 4 + r, query group g's column jq).  Every lane
-            // screens its pairs, reserves room for all of its survivors with ONE LDS atomic and stores them.
-            const int32_t* ridx = rowidx + (it & 3u) * 64;
-            const float* rnrm = rownorm + (it & 3u) * 64;
-#pragma unroll
-            for (int g = 0; g < NGW; ++g) {
-                if (!gact[g]) continue;                            // wave-uniform
-                const uint32_t qi = my_qi[g];
-                const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[qi].tau);
+            // results: acc[i][r] = dot(row slot (sub0 + i) * 16 + kq * 4 + r, query column jq of the wave's group).  Every
+            // lane screens its pairs, reserves room for all of its survivors with ONE LDS atomic and stores them.
+            if (gact) {
+                const int32_t* ridx = rowidx + (it % MW_RING) * 64;
+                const float* rnrm = rownorm + (it % MW_RING) * 64;
+                const uint32_t qi = my_qi;
+                const uint64_t tau = lds_peek(&ctrl[qi].tau);
                 const bool qok = qi < q_count;
                 // screening test in float: a value is a candidate unless it is greater than the threshold's distance
                 // (NaN values and an open / NaN threshold pass): a superset of `key < tau`, never a missing candidate
                 const bool open = tau == KEY_EMPTY;
                 const float tau_f = mono_to_float((uint32_t) (tau >> 32));
-                float vv[NS * 4];
                 uint32_t pmask = 0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
@@ -283,8 +328,7 @@ __global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2)
                     const float nx4[4] = {rn.x, rn.y, rn.z, rn.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = screen_value<METRIC>(acc[g][i][r], nx4[r], my_qn[g]);
-                        vv[i * 4 + r] = v;
+                        const float v = screen_value<METRIC>(acc[i][r], nx4[r], my_qn);
                         if (qok && rows4[r] >= 0 && (open || !(v > tau_f))) pmask |= 1u << (i * 4 + r);
                     }
                 }
@@ -298,9 +342,10 @@ __global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2)
                     uint64_t* dst = cand + (size_t) qi * cand_qstride + base;
 #pragma unroll
                     for (int j = 0; j < NS * 4; ++j)
-                        if (pmask & (1u << j)) {                   // the key is built for survivors only
-                            const int32_t row = ridx[((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3)];
-                            dst[__popc(pmask & ((1u << j) - 1u))] = make_key(vv[j], (uint32_t) row);
+                        if (pmask & (1u << j)) {                   // value and key are (re)built for survivors only
+                            const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
+                            const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
+                            dst[__popc(pmask & ((1u << j) - 1u))] = make_key(v, (uint32_t) ridx[slot]);
                         }
                 }
             }
@@ -308,11 +353,11 @@ __global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2)
             if (it + 1 < n_it && (it + 1) % MW_VOTE == 0) {        // compaction vote (between two votes a query gains
                 bool need = false;                                 // at most 64 * MW_VOTE keys: the buffers' slack)
                 for (uint32_t q = (uint32_t) tid; q < q_count; q += MW_THREADS)
-                    need |= *reinterpret_cast<volatile uint32_t*>(&ctrl[q].count) > trigger;
+                    need |= lds_peek(&ctrl[q].count) > trigger;
                 const uint32_t fslot = round % 3;
                 if (need) atomicOr(&flags[fslot], 1u);
                 __syncthreads();                                   // also: every wave is done with the stage buffers
-                const bool any = *reinterpret_cast<volatile uint32_t*>(&flags[fslot]) != 0;
+                const bool any = lds_peek(&flags[fslot]) != 0;
                 if (tid == 0) flags[(round + 2) % 3] = 0;
                 ++round;
                 if (any) {
@@ -329,12 +374,21 @@ __global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2)
                     }
                 }
             }
+        };
+        // the loop body is branch-free around its loads and exactly periodic (the tile count is padded to a multiple of
+        // DEPTH with all-invalid tiles) so that the compiler can COUNT the outstanding loads across the back edge
+        for (uint32_t it = 0; it < n_pad; it += DEPTH) {
+            tile(std::integral_constant<int, 0>{}, it);
+            if constexpr (DEPTH > 1) tile(std::integral_constant<int, 1>{}, it + 1);
+            if constexpr (DEPTH > 2) tile(std::integral_constant<int, 2>{}, it + 2);
+            if constexpr (DEPTH > 3) tile(std::integral_constant<int, 3>{}, it + 3);
         }
     };
     if (rsplit == 4) run(std::integral_constant<int, 1>{});
     else if (rsplit == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 4>{});
 
+    if (bad_row) atomicOr(p.err, 1u);                                          // a tile reached past the corpus: results invalid
     __syncthreads();
     constexpr int PR = 32;                                                     // candidate keys per lane at publish
     if (cap <= (uint32_t) (64 * PR)) {
@@ -388,9 +442,8 @@ __global__ __launch_bounds__(MW_THREADS, NGW == 1 && NSTR <= 2 ? VSR_MW_OCC : 2)
 template <int METRIC>
 hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
 {
-    const uint32_t nstage = p.pstride4 / MW_S;
-    const int ngw = p.qmax > (uint32_t) (MF_NQ * MW_WAVES) ? 2 : 1;
-    const size_t lds = mfmaw_lds_bytes(p.cap, ngw);
+    const uint32_t nch = p.pstride4 / MW_S;
+    const size_t lds = mfmaw_lds_bytes(p.cap);
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -401,14 +454,17 @@ hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream
         return hipGetLastError();
     };
     const bool sample = p.sample_stride > 1;
-    auto pick = [&](auto nstr) -> hipError_t {
-        constexpr int N = decltype(nstr)::value;
-        if constexpr (N <= 2)                                                  // two query groups per wave: B fragments fit for d <= 128
-            if (ngw == 2) return sample ? launch(mfma_wide_kernel<METRIC, N, true, 2>) : launch(mfma_wide_kernel<METRIC, N, false, 2>);
-        if (ngw == 2) return hipErrorInvalidValue;
-        return sample ? launch(mfma_wide_kernel<METRIC, N, true, 1>) : launch(mfma_wide_kernel<METRIC, N, false, 1>);
+    auto pick = [&](auto nchc) -> hipError_t {
+        constexpr int N = decltype(nchc)::value;
+        constexpr int D = mw_depth(N);
+        if (p.plane_ho) {
+            if constexpr (N <= 2)                                              // hi-only: 128 floats per stage, d <= 192 -> <= 2 stages
+                return sample ? launch(mfma_wide_kernel<METRIC, N, true, true, D>) : launch(mfma_wide_kernel<METRIC, N, false, true, D>);
+            return hipErrorInvalidValue;
+        }
+        return sample ? launch(mfma_wide_kernel<METRIC, N, true, false, D>) : launch(mfma_wide_kernel<METRIC, N, false, false, D>);
     };
-    switch (nstage) {
+    switch (nch) {
     case 1: return pick(std::integral_constant<int, 1>{});
     case 2: return pick(std::integral_constant<int, 2>{});
     case 3: return pick(std::integral_constant<int, 3>{});

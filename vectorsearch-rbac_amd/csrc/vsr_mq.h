@@ -51,6 +51,8 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
     const uint32_t nstage = (stride4 + MQ_S - 1) / MQ_S;
     const uint32_t qpitch = nstage * MQ_S;                                   // float4 per query in LDS
     const uint32_t q_count = grp.q_count;
+    const auto g_tiles = as_global(grp.tiles);                                 // global_load, not flat (vsr_device.h)
+    const auto g_bitmap = as_global(grp.bitmap);
 
     float4*   stage = reinterpret_cast<float4*>(smem) + (size_t) wave * 64 * MQ_PITCH;
     int32_t*  rowidx = reinterpret_cast<int32_t*>(smem + (size_t) MQ_WAVES * 64 * MQ_PITCH * 16) + wave * 64;
@@ -102,8 +104,8 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
             const uint32_t r = (uint32_t) lane % rw;
             if (t < t1) {
                 uint32_t start, nrows;
-                if (grp.tiles) {
-                    const uint2 tl = grp.tiles[t];
+                if (g_tiles) {
+                    const uint2 tl = load_tile(g_tiles, t);
                     start = tl.x;
                     nrows = tl.y;
                 } else {
@@ -113,7 +115,7 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
                 if (r < nrows) {
                     const uint32_t row = start + r;
                     bool ok = true;
-                    if (grp.bitmap) ok = (grp.bitmap[row >> 6] >> (row & 63)) & 1ull;
+                    if (g_bitmap) ok = (g_bitmap[row >> 6] >> (row & 63)) & 1ull;
                     if (ok) myrow = (int32_t) row;
                 }
             }
@@ -165,7 +167,7 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
                 if ((uint32_t) q < q_count) {                                  // workgroup-uniform
                     const float v = rank_value<METRIC>(acc[q], rn, qnl[q]);
                     const uint64_t key = make_key(v, (uint32_t) myrow);
-                    const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[q].tau);
+                    const uint64_t tau = lds_peek(&ctrl[q].tau);
                     topk_append(cand + (size_t) q * cand_qstride, &ctrl[q], valid && key < tau, key);
                 }
             }
@@ -174,11 +176,11 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
         if (it + 1 < iters) {                                                  // workgroup-uniform vote
             bool need = false;
             for (uint32_t q = 0; q < q_count; ++q)
-                need |= *reinterpret_cast<volatile uint32_t*>(&ctrl[q].count) > trigger;
+                need |= lds_peek(&ctrl[q].count) > trigger;
             const uint32_t slot = round % 3;
             if (need && lane == 0) atomicOr(&flags[slot], 1u);
             __syncthreads();
-            const bool any = *reinterpret_cast<volatile uint32_t*>(&flags[slot]) != 0;
+            const bool any = lds_peek(&flags[slot]) != 0;
             if (tid == 0) flags[(round + 2) % 3] = 0;
             ++round;
             if (any) {

@@ -203,6 +203,7 @@ struct vsr_corpus {
     float4*     d_rows = nullptr;
     float*      d_norm2 = nullptr;
     uint4*      d_scr = nullptr;         // K2w screening planes (bf16 hi / mid split of the rows), nullptr: not built
+    uint2*      d_all_tiles = nullptr;   // identity tile list (K2w always walks an explicit list: unfiltered passes use this)
     uint32_t    pstride4 = 0;            // 16-byte chunks per plane row
     bool        scr_has_mid = true;      // false: every element is exactly a bf16 value (e.g. SIFT's 0..255 integers)
     float*      d_norm2_max = nullptr;   // max |row|^2 (error bound of K2 screening); +Inf if any |row|^2 is not finite
@@ -275,6 +276,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     HIPCHK(hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming));
     HIPCHK(hipMalloc(&ctx->d_flag_total, 64));
     HIPCHK(hipMemset(ctx->d_flag_total, 0, 64));
+    HIPCHK(hipMemset(reinterpret_cast<char*>(ctx->d_flag_total) + 32, 0xFF, 8));   // ScanParams::ones
     const char* env;
     if ((env = getenv("VSR_BLOCK_BUDGET"))) ctx->block_budget = atoi(env);
     if ((env = getenv("VSR_MIN_ROWS_PER_BLOCK"))) ctx->min_rows_per_block = std::max(1, atoi(env));
@@ -414,6 +416,7 @@ extern "C" int vsr_stats_reset(vsr_ctx* ctx)
 // corpus
 // ---------------------------------------------------------------------------------------------
 static void drop_cached_filters(vsr_corpus* c);
+static void ranges_to_tiles(const std::vector<std::pair<uint32_t, uint32_t>>& ranges, int rw, std::vector<uint2>& tiles);
 
 extern "C" int vsr_corpus_free(vsr_corpus* c)
 {
@@ -427,7 +430,7 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
 vsr_corpus::~vsr_corpus()
 {
     drop_cached_filters(this);
-    void* ptrs[] = {d_rows, d_scr, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
+    void* ptrs[] = {d_rows, d_scr, d_all_tiles, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
     for (void* p : ptrs)
         if (p) (void) hipFree(p);
 }
@@ -529,14 +532,20 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
         // K2w multiplies bf16 hi / mid planes of the rows on the matrix cores (16x the fp32 MFMA rate); the planes are a
         // second, equally large image of the corpus, built once here (288 GB of HBM: the SIFT10M planes are 5 GB)
         if (c->k2_safe && mfmaw_supported(c->stride4) && !getenv("VSR_NO_PLANES")) {
-            c->pstride4 = plane_stride4(dim);
-            HIPCHK(hipMalloc(&c->d_scr, alloc_rows * (size_t) c->pstride4 * 16 + 1024));
             uint32_t* d_any = reinterpret_cast<uint32_t*>(c->d_norm2_max) + 8;      // spare word of the 64-byte block
-            HIPCHK(launch_split_planes(c->d_rows, (uint32_t) n, c->stride4, dim, c->d_scr, c->pstride4, d_any, ctx->stream));
+            HIPCHK(launch_check_bf16_exact(c->d_rows, (uint32_t) n, c->stride4, d_any, ctx->stream));
             uint32_t any = 1;
             HIPCHK(hipMemcpyAsync(&any, d_any, sizeof any, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            c->scr_has_mid = any != 0;
+            c->scr_has_mid = any != 0 || getenv("VSR_NO_HIONLY") != nullptr;
+            c->pstride4 = plane_stride4(dim, !c->scr_has_mid);
+            HIPCHK(hipMalloc(&c->d_scr, alloc_rows * (size_t) c->pstride4 * 16 + 1024));
+            HIPCHK(launch_split_planes(c->d_rows, (uint32_t) n, c->stride4, c->d_scr, c->pstride4, !c->scr_has_mid, ctx->stream));
+            std::vector<uint2> all;
+            ranges_to_tiles({{0u, (uint32_t) n}}, c->shape.rw, all);
+            HIPCHK(hipMalloc(&c->d_all_tiles, all.size() * sizeof(uint2)));
+            HIPCHK(hipMemcpy(c->d_all_tiles, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
         }
     }
     *out = c.release();
@@ -1107,7 +1116,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     plan.k2w = plan.k2 && k2w_ok;
     plan.mq = plan.qi == 4 && mq_ok && !plan.k2;
     plan.keep = plan.k2 ? keep : (uint32_t) k;
-    if (plan.k2w) plan.qmax = plan.qmax > 64 ? 128 : 64;    // query slots per workgroup: one or two groups per wave
+    if (plan.k2w) plan.qmax = 64;                           // query slots per workgroup: one 16-query group per wave
     else if (plan.k2) plan.qmax = plan.qmax > 16 ? 32 : 16;
 
     int64_t total_rows = 0, total_cost = 0;
@@ -1140,7 +1149,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         nb = std::min<int64_t>(nb, std::max<uint32_t>(1, p.n_tiles));
         nb = std::max<int64_t>(nb, 1);
         ScanGroup g;
-        g.tiles = p.f ? p.f->d_tiles : nullptr;
+        g.tiles = p.f ? p.f->d_tiles : plan.k2w ? c->d_all_tiles : nullptr;
         g.bitmap = p.f ? p.f->d_bitmap : nullptr;
         g.n_tiles = p.n_tiles;
         g.q_begin = p.q_off;
@@ -1288,8 +1297,8 @@ static std::string scan_kernel_name(const Plan& plan, const vsr_corpus* c, int m
     char buf[160];
     const uint32_t nstage = (c->stride4 + 15) / 16;
     if (plan.k2w)
-        snprintf(buf, sizeof buf, "vsr::mfma_wide_kernel<%s, NSTR=%u, SAMPLE=false, NGW=%d> (K2w)", mname[metric], nstage,
-                 plan.qmax > 64 ? 2 : 1);
+        snprintf(buf, sizeof buf, "vsr::mfma_wide_kernel<%s, NCH=%u, SAMPLE=false, HO=%s> (K2w, bf16 %s planes)", mname[metric],
+                 c->pstride4 / 16, c->scr_has_mid ? "false" : "true", c->scr_has_mid ? "hi+mid" : "hi-only");
     else if (plan.k2)
         snprintf(buf, sizeof buf, "vsr::mfma_scan_kernel<%s, NSTR=%d, SAMPLE=false, NG=%d> (K2)", mname[metric],
                  nstage > 4 ? 0 : 4, plan.qmax > 16 ? 2 : 1);
@@ -1329,7 +1338,8 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     const size_t off_q = 0;
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
     const size_t off_qp = align_up(off_qn + (size_t) nq * sizeof(float), 256);       // K2w: query planes (device only)
-    const size_t off_g = align_up(off_qp + (plan.k2w ? (size_t) nq * c->pstride4 * 16 : 0), 256);
+    const size_t q_pstride = c->scr_has_mid ? c->pstride4 : 2 * (size_t) c->pstride4;    // query planes keep hi and mid
+    const size_t off_g = align_up(off_qp + (plan.k2w ? (size_t) nq * q_pstride * 16 : 0), 256);
     const size_t off_gs = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
     const size_t off_qs = align_up(off_gs + plan.groups_s.size() * sizeof(ScanGroup), 256);
     const size_t off_s1 = align_up(off_qs + plan.q_slots.size() * sizeof(uint32_t), 256);
@@ -1393,6 +1403,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         st.q_norm2 = reinterpret_cast<float*>(ds + off_qn);
         st.q_scr = plan.k2w ? reinterpret_cast<uint4*>(ds + off_qp) : nullptr;
         st.pstride4 = c->pstride4;
+        st.plane_ho = c->scr_has_mid ? 0u : 1u;
         st.flags = ctx->d_flags.as<int32_t>();
         st.tau = ctx->d_tau.as<uint64_t>();
         HIPCHK(launch_stage(st, ctx->stream));
@@ -1410,6 +1421,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     sp.scr = c->d_scr;
     sp.q_scr = reinterpret_cast<const uint4*>(ds + off_qp);
     sp.pstride4 = c->pstride4;
+    sp.plane_ho = c->scr_has_mid ? 0u : 1u;
     sp.partial = ctx->d_partial.as<uint64_t>();
     sp.kp = kp;
     sp.k = kp;
@@ -1418,6 +1430,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     sp.rw = (uint32_t) c->shape.rw;
     sp.cand = nullptr;
     sp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;    // bounds-guard word (checked by vsr_screening_check)
+    sp.ones = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ctx->d_flag_total) + 32);
     sp.block_map = nullptr;
     if (plan.mq || plan.k2) {
         if ((rc = ctx->d_cand.reserve(std::max<size_t>(8, (size_t) plan.n_scan_lists * cand_pitch(sp.cap) * sizeof(uint64_t))))) return rc;

@@ -76,7 +76,7 @@ __device__ __forceinline__ void reduce_slots(float* p, int lane)
     }
 }
 
-__device__ __forceinline__ uint64_t bitmap_window(const uint64_t* bm, uint32_t start)
+__device__ __forceinline__ uint64_t bitmap_window(gptr<uint64_t> bm, uint32_t start)
 {
     // the bitmap carries zero pad words, so w + 1 is always readable
     const uint32_t w = start >> 6, sh = start & 63;
@@ -137,6 +137,8 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
         if (p.groups[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
     }
     const ScanGroup grp = p.groups[lo];
+    const auto g_tiles = as_global(grp.tiles);                                 // global_load, not flat (vsr_device.h)
+    const auto g_bitmap = as_global(grp.bitmap);
     const uint32_t local_block = blockIdx.x - grp.block_begin;
     const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
     const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
@@ -178,8 +180,8 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
         tr.rn = 0.0f;
         if (t >= t1) return;
         uint32_t start, nrows;
-        if (grp.tiles) {
-            const uint2 tl = grp.tiles[t];
+        if (g_tiles) {
+            const uint2 tl = load_tile(g_tiles, t);
             start = tl.x;
             nrows = tl.y;
         } else {
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
             nrows = p.n_rows - start < (uint32_t) RW ? p.n_rows - start : (uint32_t) RW;
         }
         uint64_t mask = nrows >= 64 ? ~0ull : ((1ull << nrows) - 1ull);
-        if (grp.bitmap) mask &= bitmap_window(grp.bitmap, start);
+        if (g_bitmap) mask &= bitmap_window(g_bitmap, start);
         tr.start = start;
         tr.mask = mask;
         if (!mask) return;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
                         reduce_slots<LPR / 2, R>(acc[qi], lane);
                         const float v = rank_value<METRIC>(acc[qi][0], cur.rn, qnl[qs]);
                         const uint64_t key = make_key(v, start + row_own);
-                        const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[qs].tau);
+                        const uint64_t tau = lds_peek(&ctrl[qs].tau);
                         const bool pass = own && ok_own && qs < q_count && key < tau;
                         topk_append(keys + (size_t) qs * cap, &ctrl[qs], pass, key);
                     }
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
                     reduce_slots<LPR / 2, R>(acc[qi], lane);
                     const float v = rank_value<METRIC>(acc[qi][0], cur.rn, qnl[qi]);
                     const uint64_t key = make_key(v, start + row_own);
-                    const uint64_t tau = *reinterpret_cast<volatile uint64_t*>(&ctrl[qi].tau);
+                    const uint64_t tau = lds_peek(&ctrl[qi].tau);
                     const bool pass = own && ok_own && (uint32_t) qi < q_count && key < tau;
                     topk_append(keys + (size_t) qi * cap, &ctrl[qi], pass, key);
                 }
@@ -295,11 +297,11 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
             // overflow vote: one barrier; flag slot `round % 3`, recycled two rounds later
             bool need = false;
             for (uint32_t qs = 0; qs < q_count; ++qs)
-                need |= *reinterpret_cast<volatile uint32_t*>(&ctrl[qs].count) > trigger;
+                need |= lds_peek(&ctrl[qs].count) > trigger;
             const uint32_t slot = round % 3;
             if (need && lane == 0) atomicOr(&flags[slot], 1u);
             __syncthreads();
-            const bool any = *reinterpret_cast<volatile uint32_t*>(&flags[slot]) != 0;
+            const bool any = lds_peek(&flags[slot]) != 0;
             if (tid == 0) flags[(round + 2) % 3] = 0;
             ++round;
             if (any) {
