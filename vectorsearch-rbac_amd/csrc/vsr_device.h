@@ -81,6 +81,10 @@ struct ScanParams {
     const uint4*     q_scr;        // [n_slots][pstride4]
     uint32_t         pstride4;     // 16-byte chunks per corpus plane row (plane_stride4)
     uint32_t         plane_ho;     // 1: hi-only corpus planes (every element exactly a bf16 value), 128 floats per stage
+    // K2w candidates: one buffer of capq keys per query slot, filled with returning atomics on qcnt (may exceed capq)
+    uint64_t*        qcand;        // [n_slots][capq]
+    uint32_t*        qcnt;         // [n_slots]
+    uint32_t         capq;
     const uint64_t*  ones;         // one all-ones 64-bit word (the "bitmap" of passes without a permission bitmap)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
 };
@@ -146,6 +150,10 @@ struct RerankParams {
     float*             out_dist;
     uint64_t*          out_keys;
     int32_t*           out_count;
+    // select_rerank_kernel (K2w): the query's candidates come from its global buffer, not from a list
+    const uint64_t*    qcand;          // [n_slots][capq]
+    const uint32_t*    qcnt;           // [n_slots] appended keys (may exceed capq: overflow)
+    uint32_t           capq;
     float              err_g;          // relative error bound of the screening dot product: |dot_s - dot| <= err_g |x| |q|
     int                seeded;         // thresholds were seeded from a sample: also check completeness
     const uint64_t*    tau_init;       // [n_slots] the seeds (bound on every excluded row when the list is not full)
@@ -199,23 +207,13 @@ inline uint32_t mfma_cap_for_k(uint32_t kp)
 inline int mfma_qmax(uint32_t stride4) { (void) stride4; return 32; }
 // K2w (vsr_mfmaw.h): GEMM-shaped shared passes for rows of <= 256 floats -- one 64-row tile staged per WORKGROUP and
 // multiplied against up to 64 (128 at d <= 128) queries whose B fragments live in the four waves' registers.
-constexpr uint32_t MW_VOTE = 8;                         // workgroup tiles between two compaction votes
-__host__ __device__ inline uint32_t mfmaw_slack() { return 64u * MW_VOTE; }   // keys a query can gain between two votes
-inline uint32_t mfmaw_cap_for_k(uint32_t kp)
+inline size_t mfmaw_lds_bytes()
 {
-    uint32_t cap = 512;
-    while (cap < 2 * kp + mfmaw_slack()) cap <<= 1;
-    return cap;                    // sorted in the staging LDS (grown to cap * 8 bytes): planner gate <= 8192 keys
+    return (size_t) 2 * 64 * 16 * 16 + 8 * 64 * 8;      // two 64-row x 16-chunk stage buffers + the row-mapping ring
 }
-__host__ __device__ inline uint32_t mfmaw_stage_bytes(uint32_t cap)
-{
-    const uint32_t b = cap * 8u;
-    return b > 32768u ? b : 32768u;                     // two 64-row x 64-float stage buffers, or the sort buffer
-}
-inline size_t mfmaw_lds_bytes(uint32_t cap)
-{
-    return (size_t) mfmaw_stage_bytes(cap) + 8 * 64 * 8 + (size_t) 64 * 16 + 32;     // + row-mapping ring, top-k control
-}
+constexpr uint32_t GQ_CAP = 4096;                       // candidate keys per query (one wave holds them all: 64 per lane)
+constexpr uint32_t GQ_SAMPLE_CAP = 1024;                // sampled keys per query kept for the threshold seed
+constexpr uint32_t GQ_MAX_KP = 512;                     // screening survivors the fused select + re-rank handles
 inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 48; }   // d = 61 .. 192; longer rows: K2
 inline int  mfmaw_qmax(uint32_t stride4) { (void) stride4; return 64; }
 hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
@@ -231,6 +229,10 @@ hipError_t launch_split_planes(const float4* rows, uint32_t n_rows, uint32_t str
 // relative error bound of the plane product  xh*qh + xh*qm + xm*qh  accumulated in fp32 over `dim` elements
 inline float plane_err_g(int dim) { return 3.0f * 3.8146973e-6f + (float) (3 * dim + 8) * 5.9604645e-8f; }
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
+hipError_t launch_select_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
+// threshold seeds of K2w: per query the m-th smallest of its sampled keys (low word all ones), KEY_EMPTY if fewer
+hipError_t launch_seed_select(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap, uint32_t m, uint64_t* tau,
+                              uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 64 (one wave per query) | 256 | 1024
 uint32_t select_wave_fanin(uint32_t kp);
@@ -251,6 +253,8 @@ struct StageParams {
                                    // corpus, 2 * pstride4 chunks (16 hi + 16 mid chunks per 128-float stage)
     int32_t*     flags;            // [nq] <- 0
     uint64_t*    tau;              // [nq] <- KEY_EMPTY (no seed)
+    uint32_t*    qcnt;             // [nq] <- 0: K2w candidate counts (nullptr: not used)
+    uint32_t*    scnt;             // [nq] <- 0: K2w sample counts
 };
 hipError_t launch_stage(const StageParams& p, hipStream_t s);
 hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);

@@ -564,6 +564,8 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
     if (tid == 0) {
         p.flags[s] = 0;
         p.tau[s] = KEY_EMPTY;
+        if (p.qcnt) p.qcnt[s] = 0;
+        if (p.scnt) p.scnt[s] = 0;
     }
     __syncthreads();
     if (p.q_scr) {                                           // K2w: the query's bf16 hi / mid planes
@@ -702,17 +704,14 @@ hipError_t launch_pair_distances(const float* a, const float* b, int64_t n_pairs
 // k-th result, i.e. when  (worst kept screening value) - err  <=  (k-th exact value),  err = fp32 error bound of
 // the screening arithmetic for this corpus (|x|^2 <= norm2_max).
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
+// keys[0 .. np2): the query's screening survivors (KEY_EMPTY padded) already in LDS; worst_kept: the largest kept
+// screening key when the survivor list is full, else KEY_EMPTY; force_flag: the caller already knows the result is unproven
+__device__ __forceinline__ void rerank_body(const RerankParams& p, uint32_t slot, uint64_t* keys, uint32_t np2,
+                                            uint64_t worst_kept, bool force_flag)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                   // [np2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t slot = blockIdx.x;
     const uint32_t out_slot = p.queries[slot].out_slot;
-    const uint64_t* list = p.lists + (size_t) slot * p.kp;
     const float4* q = reinterpret_cast<const float4*>(p.queries_f) + (size_t) slot * p.stride4;
-    uint32_t np2 = 2;
-    while (np2 < p.kp) np2 <<= 1;
 
     float qn_part = 0.0f;
     for (uint32_t c = lane; c < p.stride4; c += 64) {
@@ -724,11 +723,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
     const float qn = qn_part;
 
     // half a wave per candidate (32 lanes x float4 = 128 floats per step), U candidates per half-wave in flight:
-    // 2U independent row gathers per wave hide the HBM/L2 latency of these scattered 512-byte reads
-    // the survivors' screening keys first (one round trip for the whole list, not one per gather round); the exact
-    // keys overwrite them slot by slot: every slot is read by the half-wave that later writes it
-    for (uint32_t c = (uint32_t) tid; c < np2; c += 256) keys[c] = c < p.kp ? list[c] : KEY_EMPTY;
-    __syncthreads();
+    // 2U independent row gathers per wave hide the HBM/L2 latency of these scattered 512-byte reads.  The exact keys
+    // overwrite the screening keys slot by slot: every slot is read by the half-wave that later writes it
     const int half = lane >> 5, hl = lane & 31;
     constexpr int U = 4;                                                   // candidates in flight per half-wave
     for (uint32_t c0 = (uint32_t) wave * 2 * U; c0 < np2; c0 += 4 * 2 * U) {
@@ -795,10 +791,9 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
             if (keys[mid] != KEY_EMPTY) lo = mid + 1; else hi = mid;
         }
         s_count = lo;
-        int flag = 0;
+        int flag = force_flag ? 1 : 0;
         // every row outside the kept set ranks at or after `bound` in screening value: the worst kept candidate when
         // the list is full, else the seeded threshold (if any), else there is no outside row at all
-        const uint64_t worst_kept = list[p.kp - 1];                        // K5 leaves the largest kept key last
         uint64_t bound = worst_kept;
         if (bound == KEY_EMPTY && p.seeded) bound = p.tau_init[slot];
         if (bound != KEY_EMPTY) {
@@ -842,6 +837,100 @@ __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
         }
     }
     if (tid == 0) p.out_count[out_slot] = (int32_t) m;
+}
+
+__global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                   // [np2]
+    const uint32_t slot = blockIdx.x;
+    const uint64_t* list = p.lists + (size_t) slot * p.kp;
+    uint32_t np2 = 2;
+    while (np2 < p.kp) np2 <<= 1;
+    // the survivors' screening keys first (one round trip for the whole list, not one per gather round)
+    for (uint32_t c = threadIdx.x; c < np2; c += 256) keys[c] = c < p.kp ? list[c] : KEY_EMPTY;
+    __syncthreads();
+    rerank_body(p, slot, keys, np2, list[p.kp - 1], false);              // K5 leaves the largest kept key last
+}
+
+// K2w: per query, the kp best of its candidate buffer (one wave, every key in registers, radix select) and then the
+// exact re-rank of those kp rows, in one launch.  A buffer that overflowed lost candidates: the query is flagged.
+__global__ __launch_bounds__(256) void select_rerank_kernel(const RerankParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                   // [np2]
+    __shared__ uint32_t hist[256];
+    __shared__ uint64_t s_worst;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t slot = blockIdx.x;
+    uint32_t np2 = 2;
+    while (np2 < p.kp) np2 <<= 1;
+    const uint32_t cnt = p.qcnt[slot];
+    const uint32_t n = cnt < p.capq ? cnt : p.capq;
+    if (tid < 64) {
+        constexpr int R = GQ_CAP / 64;
+        const uint64_t* cq = p.qcand + (size_t) slot * p.capq;
+        uint64_t reg[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = (uint32_t) (r * 64 + lane);
+            reg[r] = cq[i < n ? i : 0u];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((uint32_t) (r * 64 + lane) >= n) reg[r] = KEY_EMPTY;
+        uint64_t tsel, kth;
+        wave_radix_select<R>(reg, n, p.kp, hist, lane, tsel, kth);
+        const uint32_t want = wave_emit_selected<R>(reg, n, p.kp, tsel, kth, keys, lane);
+        for (uint32_t i = want + (uint32_t) lane; i < np2; i += 64) keys[i] = KEY_EMPTY;
+        if (lane == 0) s_worst = n >= p.kp ? kth : KEY_EMPTY;
+    }
+    __syncthreads();
+    rerank_body(p, slot, keys, np2, s_worst, cnt > p.capq);
+}
+
+hipError_t launch_select_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s)
+{
+    if (p.capq != GQ_CAP || p.kp > GQ_MAX_KP) return hipErrorInvalidValue;
+    uint32_t np2 = 2;
+    while (np2 < p.kp) np2 <<= 1;
+    hipLaunchKernelGGL(select_rerank_kernel, dim3(n_queries), dim3(256), (size_t) np2 * sizeof(uint64_t), s, p);
+    return hipGetLastError();
+}
+
+// Threshold seeds of K2w: per query, the m-th smallest of its sampled keys; every row ranking at or before it stays
+// eligible in the main pass (low word all ones: ties of that distance included); too few samples: no threshold.
+__global__ __launch_bounds__(256) void seed_select_kernel(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap,
+                                                          uint32_t m, uint64_t* tau, uint32_t n_queries)
+{
+    __shared__ uint32_t sm_hist[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 4 + (uint32_t) wave;
+    if (q >= n_queries) return;                              // wave-uniform; no workgroup barrier below
+    constexpr int R = GQ_SAMPLE_CAP / 64;
+    const uint32_t cnt = samp_cnt[q];
+    const uint32_t n = cnt < cap ? cnt : cap;
+    const uint64_t* cq = samp + (size_t) q * cap;
+    uint64_t reg[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t) (r * 64 + lane);
+        reg[r] = cq[i < n ? i : 0u];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if ((uint32_t) (r * 64 + lane) >= n) reg[r] = KEY_EMPTY;
+    uint64_t tsel, kth;
+    wave_radix_select<R>(reg, n, m, sm_hist[wave], lane, tsel, kth);
+    if (lane == 0) tau[q] = n >= m ? (kth | 0xFFFFFFFFull) : KEY_EMPTY;
+}
+
+hipError_t launch_seed_select(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap, uint32_t m, uint64_t* tau,
+                              uint32_t n_queries, hipStream_t s)
+{
+    if (cap != GQ_SAMPLE_CAP || m < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(seed_select_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, samp, samp_cnt, cap, m, tau, n_queries);
+    return hipGetLastError();
 }
 
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s)

@@ -25,7 +25,12 @@
 // mapping of a tile (tile descriptor -> row -> permission bit, |row|^2) is resolved by wave 0 up to 3 * DEPTH tiles
 // ahead, one dependent load per DEPTH tiles, so its latency is covered like that of the row data.
 //
-// Screening keys, candidate buffers, compaction votes and the final per-query radix selection are those of K2.
+// Candidates: every query of the call owns ONE buffer of `capq` keys in global memory (ScanParams::qcand / qcnt).  A lane
+// whose screening values pass the query's threshold reserves room with one returning atomic and stores its keys; there
+// are no per-workgroup lists, no in-kernel compaction and no publish phase.  The thresholds come from a sample pass of
+// this same kernel (SAMPLE: every ss-th tile, threshold open, the query's sample buffer) through seed_select_kernel;
+// select_rerank_kernel (vsr_kernels.hip) then picks the kp best of a query's buffer and re-ranks them exactly.  A buffer
+// that overflows (count > capq) only loses candidates and is flagged there: the caller re-runs that query exactly.
 #pragma once
 #include <type_traits>
 #include "vsr_device.h"
@@ -93,25 +98,14 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     const auto g_norm2 = as_global(p.norm2);
     const auto g_ones = as_global(p.ones);
 
-    const uint32_t pstride4 = p.pstride4, cap = p.cap, keep = p.k;
+    const uint32_t pstride4 = p.pstride4;
     const uint32_t q_count = grp.q_count;
 
-    // LDS: [stage buffers | row index ring | |row|^2 ring | top-k control | vote flags]
-    const uint32_t stage_bytes = mfmaw_stage_bytes(cap);
+    // LDS: [stage buffers | row index ring | |row|^2 ring]
     uint4*    stage = reinterpret_cast<uint4*>(smem);                           // [2][64 * MW_S]
-    unsigned char* after = smem + stage_bytes;
+    unsigned char* after = smem + 2 * MW_ROWS * MW_S * 16;
     int32_t*  rowidx = reinterpret_cast<int32_t*>(after);                       // [MW_RING][64]
     float*    rownorm = reinterpret_cast<float*>(after + MW_RING * 64 * 4);     // [MW_RING][64]
-    TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(after + MW_RING * 64 * 8);
-    uint32_t* flags = reinterpret_cast<uint32_t*>(ctrl + MW_NQ);
-    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem);
-
-    for (uint32_t qi = tid; qi < (uint32_t) MW_NQ; qi += MW_THREADS) {
-        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
-        ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
-        ctrl[qi].count = 0;
-    }
-    if (tid < 4) flags[tid] = 0;
 
     // ---- wave roles ----
     const uint32_t ngt = (q_count + MF_NQ - 1) / MF_NQ;                         // 16-query groups of this pass (1..4)
@@ -128,8 +122,12 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     bf16x8 bh[NCH][NBLK], bm[NCH][NBLK];                                        // B fragments: hi / mid planes of the query
     const uint32_t my_qi = g0 * MF_NQ + (uint32_t) jq < (uint32_t) MW_NQ ? g0 * MF_NQ + (uint32_t) jq : 0u;
     float my_qn;
+    uint32_t my_slot;
+    uint64_t my_tau;                                                            // this lane's query: threshold (KEY_EMPTY = open)
     {
         const uint32_t slot = p.q_slots[grp.q_begin + (my_qi < q_count ? my_qi : 0)];   // pad columns repeat query 0
+        my_slot = slot;
+        my_tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         my_qn = p.q_norm2[slot];
         // query planes: per stage [hi chunks | mid chunks] (8 + 8 of a 64-float stage; 16 + 16 of a 128-float one)
         const uint4* qsrc = p.q_scr + (size_t) slot * (HO ? 2 * pstride4 : pstride4);
@@ -149,9 +147,11 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     const uint32_t n_super = (t1 - t0 + tps - 1) / tps;
     const uint32_t ss = p.sample_stride;                                        // sample pass: every ss-th tile
     const uint32_t n_it = (n_super + ss - 1) / ss;
-    const uint32_t trigger = cap - mfmaw_slack();
-    uint64_t* cand = p.cand + (size_t) (grp.partial_begin + local_block) * cand_pitch(cap);
-    const size_t cand_qstride = (size_t) grp.n_blocks * cand_pitch(cap);
+    const bool qok = my_qi < q_count;
+    const bool open = my_tau == KEY_EMPTY;
+    const float tau_f = mono_to_float((uint32_t) (my_tau >> 32));
+    uint64_t* my_cand = p.qcand + (size_t) my_slot * p.capq;
+    uint32_t* my_cnt = p.qcnt + my_slot;
 
     // ---- row mapping pipeline (wave 0, lane = row slot): at tile `it` the descriptor of tile it+3*DEPTH is fetched, the
     // row / bitmap word / norm of tile it+2*DEPTH are started and those of tile it+DEPTH are written to the LDS ring, where
@@ -250,7 +250,6 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     if constexpr (DEPTH > 2) issue_tile(std::integral_constant<int, 2>{}, 2);
     if constexpr (DEPTH > 3) issue_tile(std::integral_constant<int, 3>{}, 3);
 
-    uint32_t round = 0;
     auto run = [&](auto nsc) {
         constexpr int NS = decltype(nsc)::value;                   // 16-row sub-tiles of this wave (1, 2 or 4)
         constexpr int NH = NS > 2 ? 2 : NS;                        // sub-tiles whose A fragments are live at a time
@@ -307,17 +306,12 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
             if constexpr (NCH > 2) do_stage(std::integral_constant<int, 2>{});
 
             // results: acc[i][r] = dot(row slot (sub0 + i) * 16 + kq * 4 + r, query column jq of the wave's group).  Every
-            // lane screens its pairs, reserves room for all of its survivors with ONE LDS atomic and stores them.
+            // lane screens its pairs, reserves room in its query's buffer for all of its survivors with ONE returning
+            // atomic and stores them.  Screening test in float: a value is a candidate unless it is greater than the
+            // threshold's distance (NaN values and an open / NaN threshold pass): a superset of `key <= tau`.
             if (gact) {
                 const int32_t* ridx = rowidx + (it % MW_RING) * 64;
                 const float* rnrm = rownorm + (it % MW_RING) * 64;
-                const uint32_t qi = my_qi;
-                const uint64_t tau = lds_peek(&ctrl[qi].tau);
-                const bool qok = qi < q_count;
-                // screening test in float: a value is a candidate unless it is greater than the threshold's distance
-                // (NaN values and an open / NaN threshold pass): a superset of `key < tau`, never a missing candidate
-                const bool open = tau == KEY_EMPTY;
-                const float tau_f = mono_to_float((uint32_t) (tau >> 32));
                 uint32_t pmask = 0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
@@ -333,44 +327,17 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
                     }
                 }
                 if (__ballot(pmask != 0) != 0) {                   // wave-uniform
-                    uint32_t base = 0;
-                    if (pmask) base = atomicAdd(&ctrl[qi].count, (uint32_t) __popc(pmask));
-                    if (pmask && base + (uint32_t) __popc(pmask) > cap) {      // cannot happen (append slack protocol)
-                        atomicOr(p.err, 2u);
-                        pmask = 0;
-                    }
-                    uint64_t* dst = cand + (size_t) qi * cand_qstride + base;
+                    if (pmask) {
+                        const uint32_t n = (uint32_t) __popc(pmask);
+                        const uint32_t base = atomicAdd(my_cnt, n);            // the count keeps growing past capq: overflow shows
 #pragma unroll
-                    for (int j = 0; j < NS * 4; ++j)
-                        if (pmask & (1u << j)) {                   // value and key are (re)built for survivors only
-                            const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
-                            const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
-                            dst[__popc(pmask & ((1u << j) - 1u))] = make_key(v, (uint32_t) ridx[slot]);
-                        }
-                }
-            }
-
-            if (it + 1 < n_it && (it + 1) % MW_VOTE == 0) {        // compaction vote (between two votes a query gains
-                bool need = false;                                 // at most 64 * MW_VOTE keys: the buffers' slack)
-                for (uint32_t q = (uint32_t) tid; q < q_count; q += MW_THREADS)
-                    need |= lds_peek(&ctrl[q].count) > trigger;
-                const uint32_t fslot = round % 3;
-                if (need) atomicOr(&flags[fslot], 1u);
-                __syncthreads();                                   // also: every wave is done with the stage buffers
-                const bool any = lds_peek(&flags[fslot]) != 0;
-                if (tid == 0) flags[(round + 2) % 3] = 0;
-                ++round;
-                if (any) {
-                    for (uint32_t q = 0; q < q_count; ++q) {
-                        const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
-                        if (n > trigger) {                         // only the buffers that are filling up
-                            uint64_t* cq = cand + (size_t) q * cand_qstride;
-                            for (uint32_t i = tid; i < n; i += MW_THREADS) sortbuf[i] = cq[i];
-                            __syncthreads();
-                            topk_compact<MW_THREADS>(sortbuf, &ctrl[q], keep, tid, false);
-                            for (uint32_t i = tid; i < keep; i += MW_THREADS) cq[i] = sortbuf[i];
-                            __syncthreads();
-                        }
+                        for (int j = 0; j < NS * 4; ++j)
+                            if (pmask & (1u << j)) {               // value and key are (re)built for survivors only
+                                const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
+                                const uint32_t at = base + (uint32_t) __popc(pmask & ((1u << j) - 1u));
+                                const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
+                                if (at < p.capq) my_cand[at] = make_key(v, (uint32_t) ridx[slot]);
+                            }
                     }
                 }
             }
@@ -389,61 +356,13 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     else run(std::integral_constant<int, 4>{});
 
     if (bad_row) atomicOr(p.err, 1u);                                          // a tile reached past the corpus: results invalid
-    __syncthreads();
-    constexpr int PR = 32;                                                     // candidate keys per lane at publish
-    if (cap <= (uint32_t) (64 * PR)) {
-        // publish, one wave per query: the candidates of a (workgroup, query) buffer go to registers and the `keep`
-        // smallest are picked by a radix select (vsr_topk.h).  The partial list is unordered; K5 selects again.
-        uint32_t* hist = reinterpret_cast<uint32_t*>(smem) + wave * 256;       // wave-private, the images are dead by now
-        for (uint32_t q = (uint32_t) wave; q < q_count; q += MW_WAVES) {
-            const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
-            const uint64_t* cq = cand + (size_t) q * cand_qstride;
-            uint64_t* dst = p.partial + (size_t) (grp.partial_begin + q * grp.n_blocks + local_block) * p.kp;
-            if (n <= keep) {                                                   // nothing to drop
-                for (uint32_t i = (uint32_t) lane; i < p.kp; i += 64) dst[i] = i < n ? cq[i] : KEY_EMPTY;
-                continue;
-            }
-            auto pick = [&](auto rc) {                                         // RR keys per lane cover the n candidates
-                constexpr int RR = decltype(rc)::value;
-                uint64_t reg[RR];
-#pragma unroll
-                for (int r = 0; r < RR; ++r) {
-                    const uint32_t i = (uint32_t) (r * 64 + lane);
-                    reg[r] = cq[i < n ? i : 0u];
-                }
-#pragma unroll
-                for (int r = 0; r < RR; ++r)
-                    if ((uint32_t) (r * 64 + lane) >= n) reg[r] = KEY_EMPTY;
-                uint64_t tsel, kth;
-                wave_radix_select<RR>(reg, n, keep, hist, lane, tsel, kth);
-                const uint32_t want = wave_emit_selected<RR>(reg, n, keep, tsel, kth, dst, lane);
-                for (uint32_t i = want + (uint32_t) lane; i < p.kp; i += 64) dst[i] = KEY_EMPTY;
-            };
-            if (n <= 256) pick(std::integral_constant<int, 4>{});
-            else if (n <= 512) pick(std::integral_constant<int, 8>{});
-            else if (n <= 1024) pick(std::integral_constant<int, 16>{});
-            else pick(std::integral_constant<int, PR>{});
-        }
-        return;
-    }
-    for (uint32_t q = 0; q < q_count; ++q) {
-        const uint32_t n = ctrl[q].count < cap ? ctrl[q].count : cap;
-        const uint64_t* cq = cand + (size_t) q * cand_qstride;
-        for (uint32_t i = tid; i < n; i += MW_THREADS) sortbuf[i] = cq[i];
-        __syncthreads();
-        topk_compact<MW_THREADS>(sortbuf, &ctrl[q], keep, tid, false);
-        const uint32_t m = ctrl[q].count < keep ? ctrl[q].count : keep;
-        uint64_t* dst = p.partial + (size_t) (grp.partial_begin + q * grp.n_blocks + local_block) * p.kp;
-        for (uint32_t i = tid; i < p.kp; i += MW_THREADS) dst[i] = i < m ? sortbuf[i] : KEY_EMPTY;
-        __syncthreads();
-    }
 }
 
 template <int METRIC>
 hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
 {
     const uint32_t nch = p.pstride4 / MW_S;
-    const size_t lds = mfmaw_lds_bytes(p.cap);
+    const size_t lds = mfmaw_lds_bytes();
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -119,6 +119,8 @@ struct vsr_ctx {
     DevBuf d_cand;       // K1m / K2 candidate buffers
     DevBuf d_flags;      // per-query screening flags of the last call
     DevBuf d_tau;        // seeded thresholds (sample pass)
+    DevBuf d_samp;       // K2w: per-query sample buffers
+    DevBuf d_qcnt;       // K2w: [candidate counts | sample counts]
     bool   seeding = true;        // seed thresholds of big shared passes from a 1/32 sample pass
     int64_t seed_min_rows = 2000000;
     int64_t seed_min_pass_rows = 2048;   // average rows per pass below which the warm-up it removes is too small to pay
@@ -165,6 +167,8 @@ struct vsr_ctx {
         d_cand.release();
         d_flags.release();
         d_tau.release();
+        d_samp.release();
+        d_qcnt.release();
         d_out.release();
         d_misc.release();
         h_desc.release();
@@ -968,6 +972,8 @@ struct Plan {
     uint32_t                 n_launch = 0;   // workgroups of the main launch (= block_map.size() when mapped)
     int64_t                  scan_rows = 0;
     int64_t                  scan_bytes = 0;
+    uint32_t                 seed_m = 0;       // K2w: rank of the sampled key that becomes a query's threshold
+    uint32_t                 sample_stride = 1;  // K2w: the sample launch visits every sample_stride-th tile of a workgroup
     int64_t                  scan_pairs = 0;   // sum over passes of rows * queries
     int64_t                  unique_rows = 0;  // distinct filter parts' rows (capped at the corpus size)
 
@@ -976,7 +982,7 @@ struct Plan {
         q_slots.clear(); groups.clear(); list_ids.clear(); block_map.clear(); n_launch = 0; sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
         n_blocks = 0; qi = 1; mq = false; k2 = false; k2w = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
         n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0; sel_wave = false;
-        scan_pairs = 0; unique_rows = 0;
+        scan_pairs = 0; unique_rows = 0; seed_m = 0; sample_stride = 1;
     }
 };
 
@@ -990,8 +996,9 @@ struct PassItem {
 // Queries -> passes.  A filter that is a union of permission classes (vsr_filter::parts) is scanned class by class, so
 // that every query whose role sees a class shares that class's pass: the corpus is then read at most
 // ceil(queries of the class / qmax) times per class instead of once per role partition.
-static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, int metric, bool allow_screening,
-                      const vsr_filter* const* filters, Plan& plan)
+// Returns false when the K2w plan it built cannot be seeded safely (the caller then plans again with allow_wide = false).
+static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, int metric, bool allow_screening,
+                      bool allow_wide, const vsr_filter* const* filters, Plan& plan)
 {
     auto fof = [&](uint32_t q) { return filters ? filters[q] : nullptr; };
 
@@ -1055,7 +1062,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     const uint32_t keep = (uint32_t) std::max(2 * k, 32);
     const bool k2_any = allow_screening && ctx->screening && c->k2_safe && metric != VSR_METRIC_L1 && mq_supported(c->dim) &&
                         ctx->max_qb >= 16;
-    const bool k2w_ok = k2_any && c->d_scr && mfmaw_cap_for_k(keep) <= 8192 && !ctx->no_wide;
+    const bool k2w_ok = k2_any && allow_wide && c->d_scr && keep <= GQ_MAX_KP && !ctx->no_wide && ctx->seeding;
     const bool k2_ok = k2w_ok || (k2_any && mfma_cap_for_k(keep) <= 8192 && mfma_lds_bytes(c->stride4) <= 150 * 1024);
     int qmax;
     if (k2w_ok) qmax = ctx->max_qb_set ? std::min(ctx->max_qb, mfmaw_qmax(c->stride4)) : mfmaw_qmax(c->stride4);
@@ -1140,6 +1147,8 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
 
     // blocks per pass, then the partial lists of every query as CSR (count, prefix, fill): no per-query vectors
     static thread_local std::vector<uint32_t> loff, lcur, lids, lids_s;
+    static thread_local std::vector<double> gdens;          // per group: permitted fraction of the rows its tiles cover
+    gdens.clear();
     loff.assign((size_t) nq + 1, 0);
     for (auto& p : passes) {
         if (p.n_tiles == 0 || p.rows == 0) continue;       // empty filter part: nothing to scan
@@ -1158,6 +1167,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         g.n_blocks = (uint32_t) nb;
         g.partial_begin = plan.n_partial;
         plan.groups.push_back(g);
+        gdens.push_back(p.f && p.f->scanned_rows > 0 ? (double) p.f->allowed_rows / (double) p.f->scanned_rows : 1.0);
         ScanGroup gs = g;                                   // the same pass in the sample launch (buffers alias:
         gs.n_blocks = (uint32_t) std::max<int64_t>(1, nb / seed_div);         // it finishes before the main launch)
         gs.block_begin = plan.n_blocks_s;
@@ -1205,6 +1215,45 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         for (uint32_t l = 0; l < XCDS; ++l)
             for (size_t t = 0; t < lane[l].size(); ++t) plan.block_map[t * XCDS + l] = lane[l][t];
         plan.n_launch = (uint32_t) plan.block_map.size();
+    }
+    if (plan.k2w) {
+        // K2w keeps one candidate buffer per query: no partial lists, no K5 items.  What the plan still owes is the
+        // threshold seeding: the sample launch visits every 128th tile of each (sample) workgroup, at least one, so every
+        // pass is sampled at a fraction f >= 1/128 of its rows; the m-th best sampled key of a query, m = lambda + 6 sigma
+        // + 4 with lambda = kp * f for the DENSEST pass (a larger m only loosens the threshold), admits about m / f rows:
+        // kp + 6 sqrt(kp / f) + 4 / f <= ~1700 for f >= 1/128, inside the GQ_CAP keys a query's buffer holds.  A query
+        // whose sample is too thin to reach rank m gets an open threshold; that is only safe when all of its rows fit.
+        plan.sample_stride = 128;
+        static thread_local std::vector<double> est;
+        est.assign((size_t) nq, 0.0);
+        double frac = 1.0 / plan.sample_stride;
+        for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
+            const ScanGroup& gs = plan.groups_s[gi];
+            const double rows = (double) gs.n_tiles * c->shape.rw;
+            const double t64 = std::ceil(rows / 64.0);
+            const double per_block = std::ceil(t64 / gs.n_blocks);
+            const double sampled = std::min(rows, gs.n_blocks * std::ceil(per_block / plan.sample_stride) * 64.0);
+            if (rows > 0) frac = std::max(frac, std::min(1.0, sampled / rows));
+            for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * gdens[gi];
+        }
+        const double lambda = (double) keep * frac;
+        plan.seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
+        bool ok = plan.seed_m <= GQ_SAMPLE_CAP / 2;
+        plan.selq.resize((size_t) nq);
+        for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
+            const vsr_filter* f = fof(q);
+            const int64_t allowed = f ? f->allowed_rows : c->n;
+            if (allowed > (int64_t) GQ_CAP && est[q] < 2.0 * plan.seed_m) ok = false;
+            SelectQuery sq;
+            sq.ids_begin = 0;
+            sq.n_lists = 0;
+            sq.out_slot = q;
+            sq.dst_list = SEL_FINAL;
+            sq.allowed = (uint32_t) std::min<int64_t>(allowed, 0xFFFFFFFFll);
+            sq.pad = 0;
+            plan.selq[q] = sq;
+        }
+        return ok;
     }
     for (int q = 0; q < nq; ++q) loff[(size_t) q + 1] += loff[(size_t) q];
     lcur.assign(loff.begin(), loff.end() - 1);
@@ -1286,6 +1335,7 @@ static void make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         for (size_t s = 0; s < plan.selq.size(); ++s) plan.selq[s].dst_list = plan.rerank_base + (uint32_t) s;
         plan.n_partial += (uint32_t) plan.selq.size();
     }
+    return true;
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1310,6 +1360,207 @@ static std::string scan_kernel_name(const Plan& plan, const vsr_corpus* c, int m
     return buf;
 }
 
+// K2w launch sequence (plan.k2w): staging -> sample pass -> threshold seeds -> main pass -> select + exact re-rank.
+// Five launches, one candidate buffer per query, no partial lists (see vsr_mfmaw.h).
+static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const float* h_queries, const float* d_queries, int nq,
+                       int dim, int k, int metric, int64_t* d_blk, int32_t* d_doc, int64_t* d_row, float* d_dist, int32_t* d_cnt,
+                       uint64_t* d_keys)
+{
+    const uint32_t kp = plan.keep;
+    const size_t qfloats = (size_t) c->stride4 * 4;
+    const size_t q_pstride = c->scr_has_mid ? c->pstride4 : 2 * (size_t) c->pstride4;    // query planes keep hi and mid
+    // staging block: [queries | q_norm2 | query planes || scan groups | sample groups | pass query slots | per-query items | block map]
+    const size_t off_q = 0;
+    const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
+    const size_t off_qp = align_up(off_qn + (size_t) nq * sizeof(float), 256);
+    const size_t off_g = align_up(off_qp + (size_t) nq * q_pstride * 16, 256);             // copied from here on
+    const size_t off_gs = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
+    const size_t off_qs = align_up(off_gs + plan.groups_s.size() * sizeof(ScanGroup), 256);
+    const size_t off_sq = align_up(off_qs + plan.q_slots.size() * sizeof(uint32_t), 256);
+    const size_t off_bm = align_up(off_sq + plan.selq.size() * sizeof(SelectQuery), 256);
+    const size_t total = align_up(off_bm + plan.block_map.size() * sizeof(uint2), 256);
+    // the pinned block holds only what the host writes: the queries (host API) and the descriptors
+    const size_t h_q_bytes = h_queries ? align_up((size_t) nq * qfloats * sizeof(float), 256) : 0;
+    const size_t h_total = h_q_bytes + (total - off_g);
+
+    int rc;
+    if (ctx->desc_pending) {       // the previous batch's staging kernel still owns the pinned block
+        const auto w0 = std::chrono::steady_clock::now();
+        HIPCHK(hipEventSynchronize(ctx->desc_done));
+        ctx->desc_pending = false;
+        ctx->host_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+    }
+    if ((rc = ctx->h_desc.reserve(h_total))) return rc;
+    if ((rc = ctx->d_desc.reserve(total))) return rc;
+    if ((rc = ctx->d_flags.reserve((size_t) nq * sizeof(int32_t)))) return rc;
+    if ((rc = ctx->d_tau.reserve((size_t) nq * sizeof(uint64_t)))) return rc;
+    if ((rc = ctx->d_cand.reserve((size_t) nq * GQ_CAP * sizeof(uint64_t)))) return rc;
+    if ((rc = ctx->d_samp.reserve((size_t) nq * GQ_SAMPLE_CAP * sizeof(uint64_t)))) return rc;
+    if ((rc = ctx->d_qcnt.reserve((size_t) 2 * nq * sizeof(uint32_t)))) return rc;
+    char* hs = ctx->h_desc.as<char>();
+    char* ds = ctx->d_desc.as<char>();
+    if (h_queries) {
+        float* hq = reinterpret_cast<float*>(hs);
+        for (int s = 0; s < nq; ++s) {
+            float* dst = hq + (size_t) s * qfloats;
+            memcpy(dst, h_queries + (size_t) s * dim, (size_t) dim * sizeof(float));
+            for (size_t j = (size_t) dim; j < qfloats; ++j) dst[j] = 0.0f;
+        }
+    }
+    char* hd_desc = hs + h_q_bytes;                         // host image of [off_g, total)
+    memcpy(hd_desc + (off_g - off_g), plan.groups.data(), plan.groups.size() * sizeof(ScanGroup));
+    memcpy(hd_desc + (off_gs - off_g), plan.groups_s.data(), plan.groups_s.size() * sizeof(ScanGroup));
+    memcpy(hd_desc + (off_qs - off_g), plan.q_slots.data(), plan.q_slots.size() * sizeof(uint32_t));
+    memcpy(hd_desc + (off_sq - off_g), plan.selq.data(), plan.selq.size() * sizeof(SelectQuery));
+    memcpy(hd_desc + (off_bm - off_g), plan.block_map.data(), plan.block_map.size() * sizeof(uint2));
+
+    hipEvent_t w0 = nullptr, w1 = nullptr;                  // profiling level 1: the whole search on the device
+    if (ctx->profiling == 1) {
+        w0 = take_event(ctx);
+        w1 = take_event(ctx);
+        HIPCHK(hipEventRecord(w0, ctx->stream));
+    }
+    uint32_t* qcnt = ctx->d_qcnt.as<uint32_t>();
+    uint32_t* scnt = qcnt + nq;
+    {
+        StageParams st;
+        const char* hd = reinterpret_cast<const char*>(ctx->h_desc.dp);
+        st.src16 = reinterpret_cast<const uint4*>(hd + h_q_bytes);
+        st.dst16 = reinterpret_cast<uint4*>(ds + off_g);
+        st.n16 = (uint32_t) ((total - off_g) / 16);
+        st.q_src = d_queries ? d_queries : reinterpret_cast<const float*>(hd);
+        st.q_stride = d_queries ? (uint32_t) dim : (uint32_t) qfloats;
+        st.q_dst = reinterpret_cast<float*>(ds + off_q);
+        st.dim = (uint32_t) dim;
+        st.qfloats = (uint32_t) qfloats;
+        st.nq = (uint32_t) nq;
+        st.q_norm2 = reinterpret_cast<float*>(ds + off_qn);
+        st.q_scr = reinterpret_cast<uint4*>(ds + off_qp);
+        st.pstride4 = c->pstride4;
+        st.plane_ho = c->scr_has_mid ? 0u : 1u;
+        st.flags = ctx->d_flags.as<int32_t>();
+        st.tau = ctx->d_tau.as<uint64_t>();
+        st.qcnt = qcnt;
+        st.scnt = scnt;
+        HIPCHK(launch_stage(st, ctx->stream));
+    }
+    HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
+    ctx->desc_pending = true;
+
+    ScanParams sp{};
+    sp.rows = c->d_rows;
+    sp.norm2 = c->d_norm2;
+    sp.n_rows = (uint32_t) c->n;
+    sp.stride4 = c->stride4;
+    sp.queries = reinterpret_cast<const float*>(ds + off_q);
+    sp.q_norm2 = reinterpret_cast<const float*>(ds + off_qn);
+    sp.scr = c->d_scr;
+    sp.q_scr = reinterpret_cast<const uint4*>(ds + off_qp);
+    sp.pstride4 = c->pstride4;
+    sp.plane_ho = c->scr_has_mid ? 0u : 1u;
+    sp.q_slots = reinterpret_cast<const uint32_t*>(ds + off_qs);
+    sp.kp = sp.k = kp;
+    sp.qmax = plan.qmax;
+    sp.rw = (uint32_t) c->shape.rw;
+    sp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;
+    sp.ones = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ctx->d_flag_total) + 32);
+
+    if (plan.n_blocks) {
+        // ---- sample pass: every sample_stride-th tile, open threshold, into the queries' sample buffers ----
+        hipEvent_t a0 = nullptr, a1 = nullptr;              // profiling level 1: sample pass + seed select together
+        if (ctx->profiling == 1) {
+            a0 = take_event(ctx); a1 = take_event(ctx);
+            HIPCHK(hipEventRecord(a0, ctx->stream));
+        }
+        sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_gs);
+        sp.n_groups = (uint32_t) plan.groups_s.size();
+        sp.sample_stride = plan.sample_stride;
+        sp.tau_init = nullptr;
+        sp.block_map = nullptr;
+        sp.qcand = ctx->d_samp.as<uint64_t>();
+        sp.qcnt = scnt;
+        sp.capq = GQ_SAMPLE_CAP;
+        HIPCHK(launch_mfmaw(sp, metric, plan.n_blocks_s, ctx->stream));
+        HIPCHK(launch_seed_select(ctx->d_samp.as<uint64_t>(), scnt, GQ_SAMPLE_CAP, plan.seed_m, ctx->d_tau.as<uint64_t>(),
+                                  (uint32_t) nq, ctx->stream));
+        if (a0) {
+            HIPCHK(hipEventRecord(a1, ctx->stream));
+            ctx->pending.push_back({a0, a1, 3});
+        }
+        // ---- main pass ----
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->profiling) {
+            e0 = take_event(ctx);
+            e1 = take_event(ctx);
+            HIPCHK(hipEventRecord(e0, ctx->stream));
+        }
+        sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
+        sp.n_groups = (uint32_t) plan.groups.size();
+        sp.sample_stride = 1;
+        sp.tau_init = ctx->d_tau.as<uint64_t>();
+        sp.qcand = ctx->d_cand.as<uint64_t>();
+        sp.qcnt = qcnt;
+        sp.capq = GQ_CAP;
+        if (!plan.block_map.empty() && !ctx->no_xcd_map) sp.block_map = reinterpret_cast<const uint2*>(ds + off_bm);
+        HIPCHK(launch_mfmaw(sp, metric, sp.block_map ? plan.n_launch : plan.n_blocks, ctx->stream));
+        if (e0) {
+            HIPCHK(hipEventRecord(e1, ctx->stream));
+            ctx->pending.push_back({e0, e1, 1});
+        }
+        ctx->last_kernel = scan_kernel_name(plan, c, metric);
+        ctx->stats.scan_bytes[1] += plan.scan_bytes;
+        ctx->stats.scan_rows[1] += plan.scan_rows;
+        ctx->stats.scan_pairs[1] += plan.scan_pairs;
+        ctx->stats.unique_rows[1] += plan.unique_rows;
+    }
+
+    hipEvent_t s0 = nullptr, s1 = nullptr;
+    if (ctx->profiling == 1) {
+        s0 = take_event(ctx);
+        s1 = take_event(ctx);
+        HIPCHK(hipEventRecord(s0, ctx->stream));
+    }
+    RerankParams rr{};
+    rr.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
+    rr.rows = c->d_rows;
+    rr.stride4 = c->stride4;
+    rr.queries_f = reinterpret_cast<const float*>(ds + off_q);
+    rr.kp = kp;
+    rr.k = (uint32_t) k;
+    rr.metric = metric;
+    rr.dim = c->dim;
+    rr.norm2_max = c->d_norm2_max;
+    rr.row_offset = (uint32_t) c->row_offset;
+    rr.block_ids = c->d_block;
+    rr.doc_ids = c->d_doc;
+    rr.orig_rows = c->d_orig;
+    rr.out_block = d_blk;
+    rr.out_doc = d_doc;
+    rr.out_row = d_row;
+    rr.out_dist = d_dist;
+    rr.out_keys = d_keys;
+    rr.out_count = d_cnt;
+    rr.qcand = ctx->d_cand.as<uint64_t>();
+    rr.qcnt = qcnt;
+    rr.capq = GQ_CAP;
+    rr.err_g = plane_err_g(c->dim);
+    rr.seeded = 1;
+    rr.tau_init = ctx->d_tau.as<uint64_t>();
+    rr.out_flags = ctx->d_flags.as<int32_t>();
+    rr.flagged_total = ctx->d_flag_total;
+    HIPCHK(launch_select_rerank(rr, (uint32_t) nq, ctx->stream));
+    if (s0) {
+        HIPCHK(hipEventRecord(s1, ctx->stream));
+        ctx->pending.push_back({s0, s1, 2});
+    }
+    if (w0) {
+        HIPCHK(hipEventRecord(w1, ctx->stream));
+        ctx->pending.push_back({w0, w1, 5});
+    }
+    ctx->stats.queries += nq;
+    return VSR_OK;
+}
+
 // Shared by the host and device entry points.  d_queries == nullptr: queries come from `h_queries`.
 // `ctx` is the session the search runs in (stream, workspaces, counters): the corpus's own context, or another context
 // of the same device (vsr_search_device_on) so that two batches over one corpus can be in flight at once.
@@ -1329,7 +1580,14 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     } host_timer{ctx, h0};
     static thread_local Plan plan;
     plan.reset();
-    make_plan(ctx, c, nq, k, metric, allow_screening, filters, plan);
+    if (!make_plan(ctx, c, nq, k, metric, allow_screening, true, filters, plan)) {
+        plan.reset();                                       // K2w could not be seeded safely: legacy shared passes
+        (void) make_plan(ctx, c, nq, k, metric, allow_screening, false, filters, plan);
+    }
+    if (plan.k2w) {
+        ctx->host_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
+        return search_wide(ctx, c, plan, h_queries, d_queries, nq, dim, k, metric, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys);
+    }
     ctx->host_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
 
     const uint32_t kp = plan.keep;
@@ -1337,9 +1595,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     // one staging block: [queries | q_norm2 | scan groups | sample groups | pass query slots | K5 items | list ids]
     const size_t off_q = 0;
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
-    const size_t off_qp = align_up(off_qn + (size_t) nq * sizeof(float), 256);       // K2w: query planes (device only)
-    const size_t q_pstride = c->scr_has_mid ? c->pstride4 : 2 * (size_t) c->pstride4;    // query planes keep hi and mid
-    const size_t off_g = align_up(off_qp + (plan.k2w ? (size_t) nq * q_pstride * 16 : 0), 256);
+    const size_t off_g = align_up(off_qn + (size_t) nq * sizeof(float), 256);
     const size_t off_gs = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
     const size_t off_qs = align_up(off_gs + plan.groups_s.size() * sizeof(ScanGroup), 256);
     const size_t off_s1 = align_up(off_qs + plan.q_slots.size() * sizeof(uint32_t), 256);
@@ -1389,7 +1645,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         // ONE staging kernel instead of an SDMA copy + gather + norm + two fills: it pulls the descriptor block out of
         // the pinned host buffer, pads the queries to the row stride (from the caller's device buffer, or from the
         // staged host copy), computes |q|^2 with the arithmetic of the row norms, clears the per-query flags and seeds.
-        StageParams st;
+        StageParams st{};                                   // (no query planes, no K2w counters on this path)
         const char* hd = reinterpret_cast<const char*>(ctx->h_desc.dp);
         st.src16 = reinterpret_cast<const uint4*>(hd + off_g);
         st.dst16 = reinterpret_cast<uint4*>(ds + off_g);
@@ -1401,9 +1657,6 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         st.qfloats = (uint32_t) qfloats;
         st.nq = (uint32_t) nq;
         st.q_norm2 = reinterpret_cast<float*>(ds + off_qn);
-        st.q_scr = plan.k2w ? reinterpret_cast<uint4*>(ds + off_qp) : nullptr;
-        st.pstride4 = c->pstride4;
-        st.plane_ho = c->scr_has_mid ? 0u : 1u;
         st.flags = ctx->d_flags.as<int32_t>();
         st.tau = ctx->d_tau.as<uint64_t>();
         HIPCHK(launch_stage(st, ctx->stream));
@@ -1411,21 +1664,17 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
     ctx->desc_pending = true;
 
-    ScanParams sp;
+    ScanParams sp{};
     sp.rows = c->d_rows;
     sp.norm2 = c->d_norm2;
     sp.n_rows = (uint32_t) c->n;
     sp.stride4 = c->stride4;
     sp.queries = reinterpret_cast<const float*>(ds + off_q);
     sp.q_norm2 = reinterpret_cast<const float*>(ds + off_qn);
-    sp.scr = c->d_scr;
-    sp.q_scr = reinterpret_cast<const uint4*>(ds + off_qp);
-    sp.pstride4 = c->pstride4;
-    sp.plane_ho = c->scr_has_mid ? 0u : 1u;
     sp.partial = ctx->d_partial.as<uint64_t>();
     sp.kp = kp;
     sp.k = kp;
-    sp.cap = plan.k2w ? mfmaw_cap_for_k(kp) : plan.k2 ? mfma_cap_for_k(kp) : scan_cap_for_k((int) kp, c->dim);
+    sp.cap = plan.k2 ? mfma_cap_for_k(kp) : scan_cap_for_k((int) kp, c->dim);
     sp.qmax = plan.qmax;
     sp.rw = (uint32_t) c->shape.rw;
     sp.cand = nullptr;
@@ -1501,8 +1750,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
             HIPCHK(hipEventRecord(a0, ctx->stream));
         }
         sp.kp = sp.k = SEED_LIST;
-        if (plan.k2w) HIPCHK(launch_mfmaw(sp, metric, plan.n_blocks_s, ctx->stream));
-        else if (plan.k2) HIPCHK(launch_mfma(sp, metric, plan.n_blocks_s, ctx->stream));
+        if (plan.k2) HIPCHK(launch_mfma(sp, metric, plan.n_blocks_s, ctx->stream));
         else HIPCHK(launch_mq(sp, metric, plan.n_blocks_s, ctx->stream));
         sp.kp = sp.k = kp;
         if (a0) {
@@ -1538,8 +1786,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         }
         if (!plan.block_map.empty() && !ctx->no_xcd_map) sp.block_map = reinterpret_cast<const uint2*>(ds + off_bm);
         const uint32_t launch_blocks = sp.block_map ? plan.n_launch : plan.n_blocks;
-        if (plan.k2w) HIPCHK(launch_mfmaw(sp, metric, launch_blocks, ctx->stream));
-        else if (plan.k2) HIPCHK(launch_mfma(sp, metric, launch_blocks, ctx->stream));
+        if (plan.k2) HIPCHK(launch_mfma(sp, metric, launch_blocks, ctx->stream));
         else if (plan.mq) HIPCHK(launch_mq(sp, metric, launch_blocks, ctx->stream));
         else HIPCHK(launch_scan(sp, metric, c->dim, plan.qi, plan.n_blocks, ctx->stream));
         if (e0) {
@@ -1567,7 +1814,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     sel.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
     HIPCHK(launch_select(sel, (uint32_t) nq, sel_threads, ctx->stream));
     if (plan.k2) {
-        RerankParams rr;
+        RerankParams rr{};
         rr.lists = ctx->d_partial.as<uint64_t>() + (size_t) plan.rerank_base * kp;
         rr.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
         rr.rows = c->d_rows;
@@ -1588,7 +1835,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         rr.out_dist = d_dist;
         rr.out_keys = d_keys;
         rr.out_count = d_cnt;
-        rr.err_g = plan.k2w ? plane_err_g(c->dim) : (float) (c->dim + 8) * 5.9604645e-8f;      // K2: (d + 8) * 2^-24
+        rr.err_g = (float) (c->dim + 8) * 5.9604645e-8f;    // K2's fp32 MFMA chain: (d + 8) * 2^-24
         rr.seeded = seed ? 1 : 0;
         rr.tau_init = seed ? ctx->d_tau.as<uint64_t>() : nullptr;
         rr.out_flags = ctx->d_flags.as<int32_t>();
