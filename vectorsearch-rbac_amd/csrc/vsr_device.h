@@ -212,7 +212,8 @@ inline size_t mfmaw_lds_bytes()
     return (size_t) 2 * 64 * 16 * 16 + 8 * 64 * 8;      // two 64-row x 16-chunk stage buffers + the row-mapping ring
 }
 constexpr uint32_t GQ_CAP = 4096;                       // candidate keys per query (one wave holds them all: 64 per lane)
-constexpr uint32_t GQ_SAMPLE_CAP = 1024;                // sampled keys per query kept for the threshold seed
+constexpr uint32_t GQ_SAMPLE_CAP = 4096;                // sampled keys per query kept for the threshold seed
+constexpr uint32_t GQ_MAX_ROWS = 128 * GQ_SAMPLE_CAP;   // a query's filter may admit this many rows (its 1/128 sample must fit)
 constexpr uint32_t GQ_MAX_KP = 512;                     // screening survivors the fused select + re-rank handles
 inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 48; }   // d = 61 .. 192; longer rows: K2
 inline int  mfmaw_qmax(uint32_t stride4) { (void) stride4; return 64; }
@@ -230,8 +231,9 @@ hipError_t launch_split_planes(const float4* rows, uint32_t n_rows, uint32_t str
 inline float plane_err_g(int dim) { return 3.0f * 3.8146973e-6f + (float) (3 * dim + 8) * 5.9604645e-8f; }
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
 hipError_t launch_select_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s);
-// threshold seeds of K2w: per query the m-th smallest of its sampled keys (low word all ones), KEY_EMPTY if fewer
-hipError_t launch_seed_select(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap, uint32_t m, uint64_t* tau,
+// threshold seeds of K2w: per query the m-th smallest of its sampled keys (low word all ones), KEY_EMPTY if fewer;
+// m = lambda + 6 sqrt(lambda) + 4 with lambda = kp * frac * (kept / sampled): frac = the densest pass's sampling fraction
+hipError_t launch_seed_select(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap, float kp_frac, uint64_t* tau,
                               uint32_t n_queries, hipStream_t s);
 hipError_t launch_norm_max(const float* norm2, uint32_t n, float* out_max, hipStream_t s);
 hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads, hipStream_t s);   // threads: 64 (one wave per query) | 256 | 1024

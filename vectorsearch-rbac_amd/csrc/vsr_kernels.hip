@@ -901,7 +901,7 @@ hipError_t launch_select_rerank(const RerankParams& p, uint32_t n_queries, hipSt
 // Threshold seeds of K2w: per query, the m-th smallest of its sampled keys; every row ranking at or before it stays
 // eligible in the main pass (low word all ones: ties of that distance included); too few samples: no threshold.
 __global__ __launch_bounds__(256) void seed_select_kernel(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap,
-                                                          uint32_t m, uint64_t* tau, uint32_t n_queries)
+                                                          float kp_frac, uint64_t* tau, uint32_t n_queries)
 {
     __shared__ uint32_t sm_hist[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -920,16 +920,19 @@ __global__ __launch_bounds__(256) void seed_select_kernel(const uint64_t* samp, 
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if ((uint32_t) (r * 64 + lane) >= n) reg[r] = KEY_EMPTY;
+    // a buffer that overflowed holds a subset of the sample: the effective sampling fraction shrinks with it
+    const float lambda = kp_frac * (cnt > n ? (float) n / (float) cnt : 1.0f);
+    const uint32_t m = (uint32_t) ceilf(lambda + 6.0f * sqrtf(lambda)) + 4u;
     uint64_t tsel, kth;
     wave_radix_select<R>(reg, n, m, sm_hist[wave], lane, tsel, kth);
     if (lane == 0) tau[q] = n >= m ? (kth | 0xFFFFFFFFull) : KEY_EMPTY;
 }
 
-hipError_t launch_seed_select(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap, uint32_t m, uint64_t* tau,
+hipError_t launch_seed_select(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap, float kp_frac, uint64_t* tau,
                               uint32_t n_queries, hipStream_t s)
 {
-    if (cap != GQ_SAMPLE_CAP || m < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(seed_select_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, samp, samp_cnt, cap, m, tau, n_queries);
+    if (cap != GQ_SAMPLE_CAP || !(kp_frac > 0.0f)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(seed_select_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, samp, samp_cnt, cap, kp_frac, tau, n_queries);
     return hipGetLastError();
 }
 

@@ -972,7 +972,7 @@ struct Plan {
     uint32_t                 n_launch = 0;   // workgroups of the main launch (= block_map.size() when mapped)
     int64_t                  scan_rows = 0;
     int64_t                  scan_bytes = 0;
-    uint32_t                 seed_m = 0;       // K2w: rank of the sampled key that becomes a query's threshold
+    float                    kp_frac = 0;      // K2w: kp * sampling fraction of the densest pass (expected top-kp rows in a sample)
     uint32_t                 sample_stride = 1;  // K2w: the sample launch visits every sample_stride-th tile of a workgroup
     int64_t                  scan_pairs = 0;   // sum over passes of rows * queries
     int64_t                  unique_rows = 0;  // distinct filter parts' rows (capped at the corpus size)
@@ -982,7 +982,7 @@ struct Plan {
         q_slots.clear(); groups.clear(); list_ids.clear(); block_map.clear(); n_launch = 0; sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
         n_blocks = 0; qi = 1; mq = false; k2 = false; k2w = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
         n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0; sel_wave = false;
-        scan_pairs = 0; unique_rows = 0; seed_m = 0; sample_stride = 1;
+        scan_pairs = 0; unique_rows = 0; kp_frac = 0; sample_stride = 1;
     }
 };
 
@@ -1138,12 +1138,15 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     int64_t budget = ctx->block_budget > 0 ? ctx->block_budget : 4 * cus;
     uint32_t seed_div = SEED_BLOCK_DIV;
     if (ctx->block_budget <= 0 && plan.qi == 4) {
-        const int64_t want = std::min<int64_t>(total_rows / 13000, 16 * cus);
+        // K2w keeps 3 workgroups per CU resident and its passes differ a lot in cost per row: ~4 rounds of workgroups
+        // even them out (10M rows, 1000 queries: main launch alone 0.97 -> 0.75 ms from 4 to 12 per CU)
+        const int64_t want = plan.k2w ? std::min<int64_t>(total_rows / 4096, 12 * cus) : std::min<int64_t>(total_rows / 13000, 16 * cus);
         if (want > budget) {
             budget = want;
             seed_div = std::max<uint32_t>(seed_div, (uint32_t) (budget / (2 * cus)));
         }
     }
+    if (plan.k2w) seed_div = std::max<uint32_t>(seed_div, 8);     // the sample launch: few workgroups, several tiles each
 
     // blocks per pass, then the partial lists of every query as CSR (count, prefix, fill): no per-query vectors
     static thread_local std::vector<uint32_t> loff, lcur, lids, lids_s;
@@ -1237,13 +1240,17 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
             for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * gdens[gi];
         }
         const double lambda = (double) keep * frac;
-        plan.seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
-        bool ok = plan.seed_m <= GQ_SAMPLE_CAP / 2;
+        const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
+        plan.kp_frac = (float) lambda;
+        bool ok = seed_m <= GQ_SAMPLE_CAP / 4;
         plan.selq.resize((size_t) nq);
         for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
             const vsr_filter* f = fof(q);
             const int64_t allowed = f ? f->allowed_rows : c->n;
-            if (allowed > (int64_t) GQ_CAP && est[q] < 2.0 * plan.seed_m) ok = false;
+            // the sample of a query must fit its buffer (a bigger filter would be seeded from a thin subset and admit more
+            // rows than its candidate buffer holds), and be thick enough to reach rank m unless all of its rows fit anyway
+            if (allowed > (int64_t) GQ_MAX_ROWS) ok = false;
+            if (allowed > (int64_t) GQ_CAP && est[q] < 2.0 * seed_m) ok = false;
             SelectQuery sq;
             sq.ids_begin = 0;
             sq.n_lists = 0;
@@ -1481,7 +1488,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.qcnt = scnt;
         sp.capq = GQ_SAMPLE_CAP;
         HIPCHK(launch_mfmaw(sp, metric, plan.n_blocks_s, ctx->stream));
-        HIPCHK(launch_seed_select(ctx->d_samp.as<uint64_t>(), scnt, GQ_SAMPLE_CAP, plan.seed_m, ctx->d_tau.as<uint64_t>(),
+        HIPCHK(launch_seed_select(ctx->d_samp.as<uint64_t>(), scnt, GQ_SAMPLE_CAP, plan.kp_frac, ctx->d_tau.as<uint64_t>(),
                                   (uint32_t) nq, ctx->stream));
         if (a0) {
             HIPCHK(hipEventRecord(a1, ctx->stream));
