@@ -49,8 +49,14 @@ class ShardedSearcher:
         import torch
         if "pack" in local:                     # one collective: the rank's whole result as one packed record
             t = local["pack"]
-            g = torch.empty((self.world * t.shape[0],), dtype=t.dtype, device=t.device)
-            self.dist.all_gather_into_tensor(g, t, group=self.group)
+            if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # rehearsal on one GPU box (all ranks on GPU 0): gloo moves host memory, RCCL would move device memory
+                gh = torch.empty((self.world * t.shape[0],), dtype=t.dtype)
+                self.dist.all_gather_into_tensor(gh, t.cpu(), group=self.group)
+                g = gh.to(t.device)
+            else:
+                g = torch.empty((self.world * t.shape[0],), dtype=t.dtype, device=t.device)
+                self.dist.all_gather_into_tensor(g, t, group=self.group)
             return self.engine.merge_packed(g, local["keys"].shape[0], k)
         gathered = {}
         for name in ("keys", "block", "doc", "dist"):
