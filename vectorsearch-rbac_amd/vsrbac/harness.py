@@ -90,8 +90,11 @@ def merge_results(all_results, topk):
 class Deployment:
     """A corpus + RBAC tables resident on one GPU, exposing the reference's search functions."""
 
-    def __init__(self, ctx, rows, block_ids, doc_ids, user_roles, permissions, block_content=None):
+    def __init__(self, ctx, rows, block_ids, doc_ids, user_roles, permissions, block_content=None, metric="l2"):
+        """`metric`: the operator of the search SQL.  The reference's harness issues `vector <-> %s` (L2) everywhere
+        (prefilter_role.py:128-172, search.py:86-97); BASELINE config 3 asks for cosine (`<=>`)."""
         self.ctx = ctx
+        self.metric = metric
         self.corpus = ctx.load_corpus(rows, block_ids, doc_ids)
         self.corpus.load_rbac(user_roles, permissions)
         self.block_content = block_content          # optional: row index -> text (the table's block_content column)
@@ -132,14 +135,14 @@ class Deployment:
     def search_documents_role_partition(self, user_id, query_vector, topk=5, statistics_type="sql"):
         q = parse_vector(query_vector)
         f = self.corpus.filter_for_user(user_id, RANGES)     # union of the user's role partitions, each row once
-        res, secs = self._timed(statistics_type, lambda: self.corpus.search(q, topk, "l2", [f]))
+        res, secs = self._timed(statistics_type, lambda: self.corpus.search(q, topk, self.metric, [f]))
         return self._rows(res), secs
 
     # ---- RLS post-filter ----------------------------------------------------------------------
     def search_documents_rls(self, user_id, query_vector, topk=5, statistics_type="sql"):
         q = parse_vector(query_vector)
         f = self.corpus.filter_for_user(user_id, BITMAP)
-        res, secs = self._timed(statistics_type, lambda: self.corpus.search(q, topk, "l2", [f]))
+        res, secs = self._timed(statistics_type, lambda: self.corpus.search(q, topk, self.metric, [f]))
         return self._rows(res), secs
 
     # ---- dynamic partitions ---------------------------------------------------------------------
@@ -185,7 +188,7 @@ class Deployment:
             return [], 0.0
         filters = [self._partition_filter(p, user_id) for p in pids]
         qs = np.repeat(q[None, :], len(pids), axis=0)
-        res, secs = self._timed(statistics_type, lambda: self.corpus.search(qs, topk, "l2", filters))
+        res, secs = self._timed(statistics_type, lambda: self.corpus.search(qs, topk, self.metric, filters))
         all_rows = []
         for i in range(len(pids)):
             all_rows.extend(self._rows(res, i))
