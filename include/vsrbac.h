@@ -174,6 +174,14 @@ int vsr_merge_topk_packed_device(vsr_ctx* ctx, const void* d_packed, int n_parts
 int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, const float* b, int64_t n_pairs,
                        int dim_a, int dim_b, int b_broadcast, double* out);
 
+/* opclass support functions for n vectors at once (host pointers): vector_norm (vector.c:756-769), l2_normalize
+ * (vector.c:774-808; fails with "value out of range: overflow" like float_overflow_error) and
+ * vector_spherical_distance (vector.c:692-711; unit vectors assumed, as IVFFlat's spherical k-means uses it) */
+int vsr_vector_norms(vsr_ctx* ctx, const float* a, int64_t n, int dim, double* out);
+int vsr_l2_normalize(vsr_ctx* ctx, const float* a, int64_t n, int dim, float* out);
+int vsr_spherical_distances(vsr_ctx* ctx, const float* a, const float* b, int64_t n, int dim_a, int dim_b, int b_broadcast,
+                            double* out);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 typedef struct {
     /* K1 launches by kernel class: [0] = one query per pass, [1] = up to 4 queries sharing a pass */

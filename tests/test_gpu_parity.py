@@ -76,6 +76,36 @@ def test_pair_distance_known_answers(ctx, known):
             assert got == want
 
 
+def test_opclass_support_functions(ctx, oracle, known):
+    """vector_norm / l2_normalize / vector_spherical_distance on the device: pgvector's regress expectations
+    (vector_type.out:337-371, 537-565) and the oracle's restatement of vector.c:692-711,756-808 on random rows."""
+    import vsrbac
+    for v, want in known["norms"]:
+        assert ctx.vector_norms([v])[0] == want
+    assert float(np.float32(ctx.vector_norms([[3e37, 4e37]])[0])) == float(np.float32(5e37))
+    np.testing.assert_array_equal(ctx.l2_normalize([[3, 4]])[0], np.asarray([0.6, 0.8], dtype=np.float32))
+    np.testing.assert_array_equal(ctx.l2_normalize([[3, 0]])[0], np.asarray([1, 0], dtype=np.float32))
+    np.testing.assert_array_equal(ctx.l2_normalize([[0, 0.1]])[0], np.asarray([0, 1], dtype=np.float32))
+    np.testing.assert_array_equal(ctx.l2_normalize([[0, 0]])[0], np.asarray([0, 0], dtype=np.float32))
+    np.testing.assert_array_equal(ctx.l2_normalize([[3e38]])[0], np.asarray([1], dtype=np.float32))
+    rng = np.random.default_rng(91)
+    x = rng.normal(size=(50, 300)).astype(np.float32)
+    got_n = ctx.vector_norms(x)
+    got_u = ctx.l2_normalize(x)
+    for i in range(50):
+        assert abs(got_n[i] - oracle.vector_norm(x[i])) <= 1e-12 * got_n[i]
+        np.testing.assert_allclose(got_u[i], oracle.l2_normalize(x[i]), rtol=2e-7, atol=0)
+    y = got_u[::-1].copy()
+    got_s = ctx.spherical_distances(got_u, y)
+    for i in range(50):
+        assert abs(got_s[i] - oracle.pair("spherical_distance", got_u[i], y[i])) <= 1e-6
+    assert ctx.spherical_distances([[1.0, 0.0]], [1.0, 0.0])[0] == 0.0           # clamp, then acos(1) / pi
+    assert ctx.spherical_distances([[1.0, 0.0]], [-1.0, 0.0])[0] == 1.0
+    with pytest.raises(vsrbac.VsrError) as e:
+        ctx.spherical_distances([[1.0, 0.0]], [1.0])
+    assert str(e.value) == "different vector dimensions 2 and 1"
+
+
 def test_ordering_known_answers(ctx, known):
     o = known["ordering"]
     rows = np.asarray(o["rows"], dtype=np.float32)

@@ -266,6 +266,8 @@ hipError_t launch_pack_bytemask(const uint8_t* mask_by_orig_row, const int64_t* 
                                 uint64_t* bitmap, hipStream_t s);
 hipError_t launch_pair_distances(const float* a, const float* b, int64_t n_pairs, int dim, int b_broadcast,
                                  int metric, double* out, hipStream_t s);
+hipError_t launch_vector_fn(int mode, const float* a, const float* b, int64_t n, int dim, int b_broadcast, double* out_d,
+                            float* out_f, int* overflow, hipStream_t s);
 hipError_t launch_merge_lists(const uint64_t* keys, const int64_t* blocks, const int32_t* docs, const float* dist,
                               uint32_t n_parts, uint32_t n_queries, uint32_t k, size_t part_stride, int64_t* out_block,
                               int32_t* out_doc, float* out_dist, uint64_t* out_keys, int32_t* out_count,

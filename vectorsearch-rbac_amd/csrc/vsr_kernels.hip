@@ -698,6 +698,58 @@ hipError_t launch_pair_distances(const float* a, const float* b, int64_t n_pairs
 }
 
 // -------------------------------------------------------------------------------------------------
+// Support functions of the cosine / inner-product opclasses and of IVFFlat's spherical k-means, batched: vector_norm
+// (vector.c:756-769: sum of squares in double), l2_normalize (vector.c:774-808: x / norm in double, rounded to float4,
+// zero vector stays zero, overflow reported) and vector_spherical_distance (vector.c:692-711: acos(clamp(fp32 dot)) / pi).
+// One wave per vector; mode 0 = norm, 1 = normalize, 2 = spherical distance.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vector_fn_kernel(int mode, const float* a, const float* b, int64_t n, int dim, int b_broadcast,
+                                                        double* out_d, float* out_f, int* overflow)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t) blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t) gridDim.x * 256) >> 6;
+    for (int64_t i = wave; i < n; i += n_waves) {
+        const float* x = a + i * dim;
+        if (mode == 2) {
+            const float* y = b_broadcast ? b : b + i * dim;
+            float s = 0.0f;
+            for (int j = lane; j < dim; j += 64) s = fmaf(x[j], y[j], s);
+            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+            double d = (double) s;
+            if (d > 1) d = 1; else if (d < -1) d = -1;
+            if (lane == 0) out_d[i] = acos(d) / 3.14159265358979323846;
+            continue;
+        }
+        double norm = 0.0;
+        for (int j = lane; j < dim; j += 64) norm += (double) x[j] * (double) x[j];
+        for (int m = 32; m >= 1; m >>= 1) norm += __shfl_xor(norm, m);
+        norm = sqrt(norm);
+        if (mode == 0) {
+            if (lane == 0) out_d[i] = norm;
+        } else {
+            bool inf = false;
+            for (int j = lane; j < dim; j += 64) {
+                const float r = norm > 0 ? (float) ((double) x[j] / norm) : 0.0f;
+                out_f[i * dim + j] = r;
+                inf |= isinf(r);
+            }
+            if (__ballot(inf) != 0 && lane == 0) atomicOr(overflow, 1);
+        }
+    }
+}
+
+hipError_t launch_vector_fn(int mode, const float* a, const float* b, int64_t n, int dim, int b_broadcast, double* out_d,
+                            float* out_f, int* overflow, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(vector_fn_kernel, dim3((uint32_t) blocks), dim3(256), 0, s, mode, a, b, n, dim, b_broadcast, out_d, out_f, overflow);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
 // K5r: exact re-rank after K2's screening.  One workgroup per query; one wave per candidate recomputes the
 // operator arithmetic of vector.c (fp32 accumulation, float8 post-processing), then the kp exact keys are
 // sorted and the first k reported.  A query is flagged when a row OUTSIDE the kept set could still beat the

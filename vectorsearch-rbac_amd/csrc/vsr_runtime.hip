@@ -2057,3 +2057,52 @@ extern "C" int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, cons
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return VSR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// opclass support functions, batched (vector.c:692-711, 756-808)
+// ---------------------------------------------------------------------------------------------
+static int vector_fn(vsr_ctx* ctx, int mode, const float* a, const float* b, int64_t n, int dim_a, int dim_b, int b_broadcast,
+                     double* out_d, float* out_f, const char* who)
+{
+    if (!ctx || n < 0 || (n > 0 && (!a || (mode == 2 && !b) || (mode == 1 ? !out_f : !out_d))))
+        return fail(VSR_ERR_INVALID, "%s: NULL argument", who);
+    if (mode == 2 && dim_a != dim_b) return fail(VSR_ERR_DIM_MISMATCH, "different vector dimensions %d and %d", dim_a, dim_b);
+    if (dim_a < 1) return fail(VSR_ERR_INVALID, "%s: dim %d", who, dim_a);
+    if (n == 0) return VSR_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t a_bytes = (size_t) n * dim_a * sizeof(float);
+    const size_t b_bytes = mode == 2 ? (size_t) (b_broadcast ? 1 : n) * dim_a * sizeof(float) : 0;
+    const size_t o_bytes = mode == 1 ? a_bytes : (size_t) n * sizeof(double);
+    const size_t o_b = align_up(a_bytes, 256), o_out = align_up(o_b + b_bytes, 256), o_flag = align_up(o_out + o_bytes, 256);
+    int rc = ctx->d_misc.reserve(o_flag + 64);
+    if (rc) return rc;
+    char* d = ctx->d_misc.as<char>();
+    HIPCHK(hipMemcpyAsync(d, a, a_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (b_bytes) HIPCHK(hipMemcpyAsync(d + o_b, b, b_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(d + o_flag, 0, 4, ctx->stream));
+    HIPCHK(launch_vector_fn(mode, reinterpret_cast<float*>(d), reinterpret_cast<float*>(d + o_b), n, dim_a, b_broadcast,
+                            reinterpret_cast<double*>(d + o_out), reinterpret_cast<float*>(d + o_out),
+                            reinterpret_cast<int*>(d + o_flag), ctx->stream));
+    int overflow = 0;
+    HIPCHK(hipMemcpyAsync(mode == 1 ? (void*) out_f : (void*) out_d, d + o_out, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&overflow, d + o_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (overflow) return fail(VSR_ERR_INVALID, "value out of range: overflow");        // float_overflow_error(), vector.c:803
+    return VSR_OK;
+}
+
+extern "C" int vsr_vector_norms(vsr_ctx* ctx, const float* a, int64_t n, int dim, double* out)
+{
+    return vector_fn(ctx, 0, a, nullptr, n, dim, dim, 0, out, nullptr, "vsr_vector_norms");
+}
+
+extern "C" int vsr_l2_normalize(vsr_ctx* ctx, const float* a, int64_t n, int dim, float* out)
+{
+    return vector_fn(ctx, 1, a, nullptr, n, dim, dim, 0, nullptr, out, "vsr_l2_normalize");
+}
+
+extern "C" int vsr_spherical_distances(vsr_ctx* ctx, const float* a, const float* b, int64_t n, int dim_a, int dim_b,
+                                       int b_broadcast, double* out)
+{
+    return vector_fn(ctx, 2, a, b, n, dim_a, dim_b, b_broadcast, out, nullptr, "vsr_spherical_distances");
+}

@@ -54,6 +54,9 @@ SYMBOLS = {
     "vsr_packed_result_bytes": (_i64, [_i, _i]),
     "vsr_merge_topk_packed_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "vsr_pair_distances": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "vsr_vector_norms": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "vsr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "vsr_spherical_distances": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "vsr_profiling": (_i, [_vp, _i]),
     "vsr_stats_get": (_i, [_vp, C.POINTER(Stats)]),
     "vsr_stats_reset": (_i, [_vp]),

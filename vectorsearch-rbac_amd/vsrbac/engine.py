@@ -106,6 +106,31 @@ class Context:
                                            a.shape[1], b2.shape[1], int(bcast), _ptr(out)))
         return out
 
+    def vector_norms(self, a):
+        """vector_norm of every row (vector.c:756-769)."""
+        a = np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float32)))
+        out = np.empty(a.shape[0], dtype=np.float64)
+        check(self._lib.vsr_vector_norms(self._h, _ptr(a), a.shape[0], a.shape[1], _ptr(out)))
+        return out
+
+    def l2_normalize(self, a):
+        """l2_normalize of every row (vector.c:774-808); raises VsrError('value out of range: overflow')."""
+        a = np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float32)))
+        out = np.empty_like(a)
+        check(self._lib.vsr_l2_normalize(self._h, _ptr(a), a.shape[0], a.shape[1], _ptr(out)))
+        return out
+
+    def spherical_distances(self, a, b):
+        """vector_spherical_distance(a[i], b[i]) (vector.c:692-711); b may be a single vector."""
+        a = np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float32)))
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.float32))
+        bcast = b.ndim == 1
+        b2 = np.atleast_2d(b)
+        out = np.empty(a.shape[0], dtype=np.float64)
+        check(self._lib.vsr_spherical_distances(self._h, _ptr(a), _ptr(b2), a.shape[0], a.shape[1], b2.shape[1], int(bcast),
+                                                _ptr(out)))
+        return out
+
     def merge_topk_device(self, keys, block_ids, doc_ids, dist, n_parts, nq, k, out_block, out_doc, out_dist,
                           out_keys, out_counts):
         """Device pointers (ints).  Layout [n_parts][nq][k]."""
