@@ -1,0 +1,308 @@
+/*
+ * vsr_pg.c — per-backend GPU context, corpus cache, RBAC tables and GUCs of the PostgreSQL shim.
+ *
+ * Reference behaviour this file stands in for:
+ *   pgvector/src/hnsw.c:86-104, ivfflat.c:41-53      GUC definitions (hnsw.ef_search, ivfflat.probes stay pgvector's)
+ *   controller/initialize_main_tables.py:17-72       UserRoles(user_id, role_id), PermissionAssignment(role_id, document_id)
+ *   controller/baseline/pg_row_security/row_level_security.py:41-69   role per user, policy on current_user::int
+ *   controller/initialize_main_tables.py:54-61       documentblocks(block_id, document_id, block_content, vector)
+ */
+#include "vsr_pg.h"
+
+#include "access/heapam.h"
+#include "access/tableam.h"
+#include "catalog/index.h"
+#include "executor/spi.h"
+#include "executor/tuptable.h"
+#include "miscadmin.h"
+#include "storage/ipc.h"
+#include "utils/builtins.h"
+#include "utils/guc.h"
+#include "utils/hsearch.h"
+#include "utils/lsyscache.h"
+#include "utils/memutils.h"
+#include "utils/snapmgr.h"
+
+#include "vector.h"				/* pgvector's: struct Vector, DatumGetVector */
+
+int			vsr_pg_device = 0;
+int			vsr_pg_mode = VSR_PG_MODE_POSTFILTER;
+
+static const struct config_enum_entry vsr_pg_mode_options[] = {
+	{"off", VSR_PG_MODE_OFF, false},
+	{"prefilter", VSR_PG_MODE_PREFILTER, false},
+	{"postfilter", VSR_PG_MODE_POSTFILTER, false},
+	{NULL, 0, false}
+};
+
+static vsr_ctx *backend_ctx = NULL;
+static HTAB *corpus_cache = NULL;
+
+void
+VsrCheck(int status)
+{
+	if (status == VSR_OK)
+		return;
+	/* vector.c:60-67 reports dimension mismatches as ERRCODE_DATA_EXCEPTION with exactly this text */
+	ereport(ERROR,
+			(errcode(status == VSR_ERR_DIM_MISMATCH ? ERRCODE_DATA_EXCEPTION :
+					 status == VSR_ERR_OOM ? ERRCODE_OUT_OF_MEMORY : ERRCODE_EXTERNAL_ROUTINE_EXCEPTION),
+			 errmsg("%s", vsr_last_error())));
+}
+
+static void
+vsr_pg_shutdown(int code, Datum arg)
+{
+	if (backend_ctx != NULL)
+	{
+		(void) vsr_close(backend_ctx);
+		backend_ctx = NULL;
+	}
+}
+
+vsr_ctx *
+VsrBackendContext(void)
+{
+	/* never inherited across fork: a backend opens its own HIP context on first use */
+	if (backend_ctx == NULL)
+	{
+		VsrCheck(vsr_open(vsr_pg_device, &backend_ctx));
+		on_proc_exit(vsr_pg_shutdown, (Datum) 0);
+	}
+	return backend_ctx;
+}
+
+int
+VsrMetricOf(Relation index)
+{
+	/* the opclass's distance support function (proc 1) names the operator family: vector.sql:292-333 */
+	Oid			procid = index_getprocid(index, 1, 1);
+	char	   *name = get_func_name(procid);
+
+	if (strcmp(name, "vector_l2_squared_distance") == 0)
+		return VSR_METRIC_L2;
+	if (strcmp(name, "vector_negative_inner_product") == 0)
+		return index->rd_support != NULL && OidIsValid(index_getprocid(index, 1, 2)) ? VSR_METRIC_COSINE : VSR_METRIC_IP;
+	if (strcmp(name, "l1_distance") == 0 || strcmp(name, "vector_l1_distance") == 0)
+		return VSR_METRIC_L1;
+	ereport(ERROR, (errmsg("vsrbac: unsupported distance function %s", name)));
+	return VSR_METRIC_L2;		/* not reached */
+}
+
+int32
+VsrCurrentUserId(void)
+{
+	/* the reference creates one PostgreSQL role per user, named by the user id (row_level_security.py:41-52) */
+	char	   *name = GetUserNameFromId(GetUserId(), false);
+	char	   *end;
+	long		v = strtol(name, &end, 10);
+
+	return (*end == '\0' && end != name) ? (int32) v : -1;	/* not a numeric role: sees nothing under RBAC */
+}
+
+/* attribute number of a column of the heap, or 0 */
+static AttrNumber
+heap_attno(Relation heap, const char *name)
+{
+	TupleDesc	desc = RelationGetDescr(heap);
+
+	for (int i = 0; i < desc->natts; i++)
+		if (strcmp(NameStr(TupleDescAttr(desc, i)->attname), name) == 0)
+			return (AttrNumber) (i + 1);
+	return 0;
+}
+
+/* one int4 pair table through SPI: UserRoles / PermissionAssignment */
+static int64
+load_pairs(const char *sql, int32 **a, int32 **b, MemoryContext keep)
+{
+	int64		n = 0;
+
+	if (SPI_execute(sql, true, 0) != SPI_OK_SELECT)
+		return -1;				/* table absent: no RBAC */
+	n = (int64) SPI_processed;
+	*a = MemoryContextAlloc(keep, sizeof(int32) * Max(n, 1));
+	*b = MemoryContextAlloc(keep, sizeof(int32) * Max(n, 1));
+	for (int64 i = 0; i < n; i++)
+	{
+		bool		isnull;
+
+		(*a)[i] = DatumGetInt32(SPI_getbinval(SPI_tuptable->vals[i], SPI_tuptable->tupdesc, 1, &isnull));
+		(*b)[i] = DatumGetInt32(SPI_getbinval(SPI_tuptable->vals[i], SPI_tuptable->tupdesc, 2, &isnull));
+	}
+	return n;
+}
+
+VsrPgCorpus *
+VsrCorpusForIndex(Relation index)
+{
+	Oid			indexoid = RelationGetRelid(index);
+	bool		found;
+	VsrPgCorpus *pc;
+
+	if (corpus_cache == NULL)
+	{
+		HASHCTL		hc;
+
+		memset(&hc, 0, sizeof(hc));
+		hc.keysize = sizeof(Oid);
+		hc.entrysize = sizeof(VsrPgCorpus);
+		hc.hcxt = TopMemoryContext;
+		corpus_cache = hash_create("vsrbac corpora", 16, &hc, HASH_ELEM | HASH_BLOBS | HASH_CONTEXT);
+	}
+	pc = hash_search(corpus_cache, &indexoid, HASH_ENTER, &found);
+	if (found && pc->corpus != NULL)
+		return pc;
+
+	{
+		Relation	heap = table_open(index->rd_index->indrelid, AccessShareLock);
+		AttrNumber	vec_att = index->rd_index->indkey.values[0];
+		AttrNumber	blk_att = heap_attno(heap, "block_id");
+		AttrNumber	doc_att = heap_attno(heap, "document_id");
+		TableScanDesc hs = table_beginscan(heap, GetActiveSnapshot(), 0, NULL);
+		TupleTableSlot *slot = table_slot_create(heap, NULL);
+		int64		cap = 1 << 16,
+					n = 0;
+		int			dim = 0;
+		float	   *rows = NULL;
+		int64	   *blk = palloc(sizeof(int64) * cap);
+		int32	   *doc = palloc(sizeof(int32) * cap);
+		ItemPointerData *tids = MemoryContextAlloc(TopMemoryContext, sizeof(ItemPointerData) * cap);
+
+		while (table_scan_getnextslot(hs, ForwardScanDirection, slot))
+		{
+			bool		isnull;
+			Datum		d = slot_getattr(slot, vec_att, &isnull);
+			Vector	   *v;
+
+			if (isnull)
+				continue;		/* NULL vectors are not indexed (hnswbuild.c:473-480) */
+			v = DatumGetVector(d);
+			if (dim == 0)
+			{
+				dim = v->dim;
+				rows = MemoryContextAllocHuge(CurrentMemoryContext, sizeof(float) * (Size) cap * dim);
+			}
+			if (n == cap)
+			{
+				cap *= 2;
+				rows = repalloc_huge(rows, sizeof(float) * (Size) cap * dim);
+				blk = repalloc_huge(blk, sizeof(int64) * cap);
+				doc = repalloc_huge(doc, sizeof(int32) * cap);
+				tids = repalloc_huge(tids, sizeof(ItemPointerData) * cap);
+			}
+			memcpy(rows + (Size) n * dim, v->x, sizeof(float) * dim);
+			blk[n] = blk_att ? DatumGetInt64(slot_getattr(slot, blk_att, &isnull)) : n;
+			doc[n] = doc_att ? DatumGetInt32(slot_getattr(slot, doc_att, &isnull)) : 0;
+			tids[n] = slot->tts_tid;
+			n++;
+		}
+		ExecDropSingleTupleTableSlot(slot);
+		table_endscan(hs);
+		table_close(heap, AccessShareLock);
+
+		pc->indexoid = indexoid;
+		pc->dim = dim;
+		pc->nrows = n;
+		pc->tids = tids;
+		pc->has_rbac = false;
+		pc->corpus = NULL;
+		VsrCheck(vsr_corpus_load(VsrBackendContext(), rows, n, dim > 0 ? dim : 1, blk_att ? blk : NULL, doc_att ? doc : NULL, 0,
+								 &pc->corpus));
+		if (rows)
+			pfree(rows);
+		pfree(blk);
+		pfree(doc);
+	}
+
+	/* RBAC tables, when the schema of the reference is present and the heap carries document ids */
+	if (SPI_connect() == SPI_OK_CONNECT)
+	{
+		int32	   *uu = NULL, *ur = NULL, *pr = NULL, *pd = NULL;
+		int64		n_ur = load_pairs("SELECT user_id, role_id FROM userroles", &uu, &ur, CurrentMemoryContext);
+		int64		n_pa = n_ur >= 0 ? load_pairs("SELECT role_id, document_id FROM permissionassignment", &pr, &pd, CurrentMemoryContext) : -1;
+
+		if (n_ur >= 0 && n_pa >= 0)
+		{
+			VsrCheck(vsr_rbac_load(pc->corpus, uu, ur, n_ur, pr, pd, n_pa));
+			pc->has_rbac = true;
+		}
+		SPI_finish();
+	}
+	return pc;
+}
+
+vsr_filter *
+VsrFilterForCurrentUser(VsrPgCorpus * pc)
+{
+	vsr_filter *f = NULL;
+
+	if (vsr_pg_mode == VSR_PG_MODE_OFF || !pc->has_rbac || superuser())
+		return NULL;
+	VsrCheck(vsr_filter_for_user(pc->corpus, VsrCurrentUserId(),
+								 vsr_pg_mode == VSR_PG_MODE_PREFILTER ? VSR_FILTER_RANGES : VSR_FILTER_BITMAP, &f));
+	return f;
+}
+
+/*
+ * The whole search, run by the first gettuple of a scan.  k_hint = hnsw.ef_search (hnswscan.c:44) or the number of rows
+ * the probed lists hold; the executor's LIMIT pops at most that many.  The result is exact filtered top-k_hint.
+ */
+void
+VsrRunSearch(IndexScanDesc scan, VsrPgScanOpaque so, int k_hint)
+{
+	VsrPgCorpus *pc = so->pc;
+	Vector	   *q;
+	const vsr_filter *filter;
+	int			k = Min(Max(k_hint, 1), VSR_MAX_K);
+	MemoryContext old = MemoryContextSwitchTo(so->tmpCtx);
+	int64	   *blk = palloc(sizeof(int64) * k);
+	int64	   *rowidx = palloc(sizeof(int64) * k);
+	float	   *dist = palloc(sizeof(float) * k);
+	int32		count = 0;
+
+	if (scan->orderByData == NULL)
+		elog(ERROR, "cannot scan index without order");	/* hnswscan.c:196-197 */
+	if (scan->orderByData->sk_flags & SK_ISNULL)
+	{
+		so->nresults = 0;		/* ORDER BY vec <-> NULL: no rows from the index (hnswscan.c:84-89 returns a zero vector scan) */
+		MemoryContextSwitchTo(old);
+		return;
+	}
+	q = DatumGetVector(scan->orderByData->sk_argument);
+	if (q->dim != pc->dim)
+		ereport(ERROR, (errcode(ERRCODE_DATA_EXCEPTION),
+						errmsg("different vector dimensions %d and %d", pc->dim, q->dim)));
+	filter = VsrFilterForCurrentUser(pc);
+	VsrCheck(vsr_search(pc->corpus, q->x, 1, q->dim, k, VsrMetricOf(scan->indexRelation), filter ? &filter : NULL,
+						blk, NULL, rowidx, dist, &count));
+	so->result_tids = palloc(sizeof(ItemPointerData) * Max(count, 1));
+	for (int i = 0; i < count; i++)
+		so->result_tids[i] = pc->tids[rowidx[i]];
+	so->nresults = count;
+	so->next = 0;
+	MemoryContextSwitchTo(old);
+}
+
+bool
+VsrNextTuple(IndexScanDesc scan, VsrPgScanOpaque so)
+{
+	if (so->next >= so->nresults)
+		return false;
+	scan->xs_heaptid = so->result_tids[so->next++];
+	scan->xs_recheck = false;	/* exact distances: hnswscan.c:308-310 */
+	scan->xs_recheckorderby = false;
+	return true;
+}
+
+void
+VsrPgInit(void)
+{
+	DefineCustomIntVariable("vsrbac.device", "HIP device ordinal of the MI355X this backend searches on", NULL,
+							&vsr_pg_device, 0, 0, 63, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomEnumVariable("vsrbac.mode", "How the current user's RBAC permissions are applied to index scans",
+							 "off: unfiltered (RLS quals filter afterwards); prefilter: read only permitted rows; "
+							 "postfilter: per-row permission bit in the distance loop", &vsr_pg_mode,
+							 VSR_PG_MODE_POSTFILTER, vsr_pg_mode_options, PGC_USERSET, 0, NULL, NULL, NULL);
+	MarkGUCPrefixReserved("vsrbac");
+}

@@ -1,0 +1,75 @@
+/*
+ * vsr_pg.h — PostgreSQL extension shim over libvsrbac (include/vsrbac.h).
+ *
+ * The shim is pgvector with its two scan state machines swapped out: the SQL surface (sql/vector.sql, vector.control),
+ * the `vector` type and its fmgr functions (src/vector.c), the index build and the access-method handlers
+ * (src/hnsw.c:263-335, src/ivfflat.c) stay pgvector's own files, compiled unchanged.  Only
+ *
+ *     pgvector/src/hnswscan.c   ->  pg_shim/vsr_hnswscan.c   (hnswbeginscan / hnswrescan / hnswgettuple / hnswendscan)
+ *     pgvector/src/ivfscan.c    ->  pg_shim/vsr_ivfscan.c    (ivfflatbeginscan / ... / ivfflatendscan)
+ *
+ * are replaced, plus pg_shim/vsr_pg.c (per-backend GPU context, corpus cache, RBAC tables, GUCs).  The Makefile builds
+ * the result as `vector.so` with PGXS when `pg_config` exists.  It is NOT compiled in the authoring image (no
+ * postgres.h there); the GPU library underneath is, and is what tests/ exercise.
+ *
+ * Single-pair operators (`SELECT a <-> b`, the Sort above a seq scan) keep calling pgvector's vector.c: one GPU launch
+ * per pair would be slower than the 128-float loop, and libvsrbac deliberately contains no CPU arithmetic (its header
+ * promises there is no CPU path).  Batched pair distances exist as vsr_pair_distances for callers that have many.
+ */
+#ifndef VSR_PG_H
+#define VSR_PG_H
+
+#include "postgres.h"
+
+#include "access/genam.h"
+#include "access/relscan.h"
+#include "storage/itemptr.h"
+#include "utils/rel.h"
+
+#include "vsrbac.h"
+
+/* how the current user's permissions are applied (GUC vsrbac.mode) */
+typedef enum
+{
+	VSR_PG_MODE_OFF,			/* no permission filter: the executor's RLS qual filters afterwards, as with stock pgvector */
+	VSR_PG_MODE_PREFILTER,		/* VSR_FILTER_RANGES: only the user's rows are read (role / partition tables) */
+	VSR_PG_MODE_POSTFILTER		/* VSR_FILTER_BITMAP: the RLS predicate as a per-row bit in the distance loop */
+}			VsrPgMode;
+
+extern int	vsr_pg_device;		/* GUC vsrbac.device */
+extern int	vsr_pg_mode;		/* GUC vsrbac.mode */
+
+/* One resident corpus per index relation, cached for the life of the backend (or of the sidecar). */
+typedef struct VsrPgCorpus
+{
+	Oid			indexoid;
+	vsr_corpus *corpus;
+	int			dim;
+	int64		nrows;
+	ItemPointerData *tids;		/* caller row index (vsr_search's out_rows) -> heap TID */
+	bool		has_rbac;
+}			VsrPgCorpus;
+
+/* scan state shared by the two access methods: the first gettuple runs the whole search, later calls pop */
+typedef struct VsrPgScanOpaqueData
+{
+	VsrPgCorpus *pc;
+	bool		first;
+	int			nresults;
+	int			next;
+	ItemPointerData *result_tids;
+	MemoryContext tmpCtx;
+}			VsrPgScanOpaqueData;
+typedef VsrPgScanOpaqueData *VsrPgScanOpaque;
+
+/* vsr_pg.c */
+extern void VsrCheck(int status);	/* ereport(ERROR) with vsr_last_error(); keeps pgvector's dimension text */
+extern vsr_ctx *VsrBackendContext(void);	/* opened lazily, after fork, once per backend */
+extern VsrPgCorpus *VsrCorpusForIndex(Relation index);	/* heap scan + vsr_corpus_load + RBAC tables on first use */
+extern int	VsrMetricOf(Relation index);	/* opclass distance proc -> VSR_METRIC_* */
+extern int32 VsrCurrentUserId(void);	/* current_user::int, the reference's RLS convention */
+extern vsr_filter *VsrFilterForCurrentUser(VsrPgCorpus * pc);	/* NULL when vsrbac.mode = off or no RBAC tables */
+extern void VsrRunSearch(IndexScanDesc scan, VsrPgScanOpaque so, int k_hint);	/* fills so->result_tids */
+extern bool VsrNextTuple(IndexScanDesc scan, VsrPgScanOpaque so);
+
+#endif							/* VSR_PG_H */

@@ -262,6 +262,8 @@ hipError_t launch_stage(const StageParams& p, hipStream_t s);
 hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);
 hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,
                                uint32_t words, const uint64_t* user_mask, uint64_t* bitmap, hipStream_t s);
+hipError_t launch_build_class_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint32_t* doc_class, uint32_t cls,
+                                     uint64_t* bitmap, hipStream_t s);
 hipError_t launch_pack_bytemask(const uint8_t* mask_by_orig_row, const int64_t* orig_rows, uint32_t n_rows,
                                 uint64_t* bitmap, hipStream_t s);
 hipError_t launch_pair_distances(const float* a, const float* b, int64_t n_pairs, int dim, int b_broadcast,

@@ -613,6 +613,25 @@ __global__ __launch_bounds__(256) void build_bitmap_kernel(const uint32_t* row_d
     if ((threadIdx.x & 63) == 0 && row < n_rows) bitmap[row >> 6] = bits;
 }
 
+// permission bitmap of ONE permission class: bit(row) = class_of_doc[doc(row)] == cls
+__global__ __launch_bounds__(256) void build_class_bitmap_kernel(const uint32_t* row_doc_idx, uint32_t n_rows,
+                                                                 const uint32_t* doc_class, uint32_t cls, uint64_t* bitmap)
+{
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    const bool allowed = row < n_rows && doc_class[row_doc_idx[row]] == cls;
+    const uint64_t bits = __ballot(allowed);
+    if ((threadIdx.x & 63) == 0 && row < n_rows) bitmap[row >> 6] = bits;
+}
+
+hipError_t launch_build_class_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint32_t* doc_class, uint32_t cls,
+                                     uint64_t* bitmap, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(build_class_bitmap_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, row_doc_idx, n_rows, doc_class,
+                       cls, bitmap);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,
                                uint32_t words, const uint64_t* user_mask, uint64_t* bitmap, hipStream_t s)
 {

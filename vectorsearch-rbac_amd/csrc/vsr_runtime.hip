@@ -232,6 +232,8 @@ struct vsr_corpus {
     std::vector<uint32_t> doc_class;                 // per document
     std::vector<std::vector<uint64_t>> class_sig;    // per class
     std::vector<vsr_filter*> class_filters;          // per class, built on first use (RANGES, owned by the corpus)
+    std::vector<vsr_filter*> class_bitmap_filters;   // per class, BITMAP mode: aligned windows + the class's own bitmap
+    uint32_t* d_doc_class = nullptr;                 // class of every document (device copy of doc_class)
 
     ~vsr_corpus();                 // frees the device arrays and cached filters (also on vsr_corpus_load's error returns)
 };
@@ -434,7 +436,7 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
 vsr_corpus::~vsr_corpus()
 {
     drop_cached_filters(this);
-    void* ptrs[] = {d_rows, d_scr, d_all_tiles, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
+    void* ptrs[] = {d_rows, d_scr, d_all_tiles, d_doc_class, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
     for (void* p : ptrs)
         if (p) (void) hipFree(p);
 }
@@ -567,6 +569,13 @@ static void drop_cached_filters(vsr_corpus* c)
             delete f;
         }
     c->class_filters.clear();
+    for (vsr_filter* f : c->class_bitmap_filters)
+        if (f) {
+            if (f->d_tiles) (void) hipFree(f->d_tiles);
+            if (f->d_bitmap && f->owns_bitmap) (void) hipFree(f->d_bitmap);
+            delete f;
+        }
+    c->class_bitmap_filters.clear();
     c->class_sig.clear();
     c->doc_class.clear();
     for (auto& kv : c->cache) {
@@ -631,6 +640,12 @@ extern "C" int vsr_rbac_load(vsr_corpus* c, const int32_t* ur_user, const int32_
             c->doc_class[di] = it->second;
         }
         c->class_filters.assign(c->class_sig.size(), nullptr);
+        c->class_bitmap_filters.assign(c->class_sig.size(), nullptr);
+        if (c->d_doc_class) (void) hipFree(c->d_doc_class);
+        c->d_doc_class = nullptr;
+        HIPCHK(hipMalloc(&c->d_doc_class, std::max<size_t>(4, c->doc_class.size() * sizeof(uint32_t))));
+        if (!c->doc_class.empty())
+            HIPCHK(hipMemcpy(c->d_doc_class, c->doc_class.data(), c->doc_class.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     c->rbac = true;
     return VSR_OK;
@@ -746,6 +761,45 @@ static int class_filter(vsr_corpus* c, uint32_t cls, vsr_filter** out)
     return VSR_OK;
 }
 
+static int alloc_bitmap(vsr_filter* f);
+static int64_t ranges_to_aligned_tiles(const std::vector<std::pair<uint32_t, uint32_t>>& ranges, int rw, int64_t n,
+                                       std::vector<uint2>& tiles);
+
+// the rows of one permission class in post-filter form: the RW-aligned windows that hold at least one of its rows and the
+// class's own permission bitmap, tested per row in the distance loop (built once, owned by the corpus)
+static int class_bitmap_filter(vsr_corpus* c, uint32_t cls, vsr_filter** out)
+{
+    if (c->class_bitmap_filters[cls]) {
+        *out = c->class_bitmap_filters[cls];
+        return VSR_OK;
+    }
+    std::unique_ptr<vsr_filter, void (*)(vsr_filter*)> f(new vsr_filter(), free_filter);
+    f->corpus = c;
+    f->mode = VSR_FILTER_BITMAP;
+    f->cached = true;
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    int64_t rows = 0;
+    for (size_t di = 0; di < c->docs.size(); ++di) {
+        if (c->doc_class[di] != cls) continue;
+        const uint32_t s = c->doc_row_start[di], e = c->doc_row_start[di + 1];
+        rows += e - s;
+        if (!ranges.empty() && ranges.back().second == s) ranges.back().second = e;
+        else ranges.emplace_back(s, e);
+    }
+    int rc = alloc_bitmap(f.get());
+    if (rc) return rc;
+    HIPCHK(launch_build_class_bitmap(c->d_row_docidx, (uint32_t) c->n, c->d_doc_class, cls, f->d_bitmap, c->ctx->stream));
+    std::vector<uint2> tiles;
+    f->scanned_rows = ranges_to_aligned_tiles(ranges, c->shape.rw, c->n, tiles);
+    rc = upload_tiles(f.get(), tiles);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->ctx->stream));
+    f->allowed_rows = rows;
+    c->class_bitmap_filters[cls] = f.release();
+    *out = c->class_bitmap_filters[cls];
+    return VSR_OK;
+}
+
 static int build_role_filter(vsr_corpus* c, const std::vector<int32_t>& roles, int mode, vsr_filter** out)
 {
     std::unique_ptr<vsr_filter, void (*)(vsr_filter*)> f(new vsr_filter(), free_filter);
@@ -794,6 +848,19 @@ static int build_role_filter(vsr_corpus* c, const std::vector<int32_t>& roles, i
         f->scanned_rows = ranges_to_aligned_tiles(ranges, c->shape.rw, c->n, tiles);
         rc = upload_tiles(f.get(), tiles);
         if (rc) return rc;
+        // the same row set class by class, each class with its own bitmap: queries of different roles then share the
+        // classes they have in common exactly as in pre-filter mode (the bit test per row stays in the distance loop)
+        if (c->class_sig.size() <= MAX_CLASSES) {
+            for (uint32_t cls = 0; cls < (uint32_t) c->class_sig.size(); ++cls) {
+                bool hit = false;
+                for (uint32_t w = 0; w < c->words; ++w) hit |= (c->class_sig[cls][w] & m[w]) != 0;
+                if (!hit) continue;
+                vsr_filter* part = nullptr;
+                if ((rc = class_bitmap_filter(c, cls, &part))) return rc;
+                if (part->n_tiles) f->parts.push_back(part);
+            }
+            if (f->parts.size() > MAX_PARTS || f->parts.size() < 2) f->parts.clear();
+        }
     }
     *out = f.release();
     return VSR_OK;
