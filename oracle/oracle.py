@@ -56,6 +56,14 @@ def _bind(lib):
         "orc_recall": (d, [_i32p, _i64p, i64, _i32p, _i64p, i64]),
         "orc_search_ranges": (None, [i, _f32p, i64, i, vp, vp, _f32p, i64, i64, _i64p, _i64p,
                                      _i64p, _f64p, _i64p]),
+        "orc_ivf_kmeans": (i, [i, i, _f32p, i64, i, C.c_uint64, _f32p]),
+        "orc_ivf_assign": (None, [i, i, _f32p, i64, _f32p, i, _i32p]),
+        "orc_ivf_probe": (i, [i, i, _f32p, i, _f32p, i, _i32p]),
+        "orc_hnsw_build": (vp, [i, _f32p, i64, i, i, i, C.c_uint64]),
+        "orc_hnsw_free": (None, [vp]),
+        "orc_hnsw_info": (None, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "orc_hnsw_export": (None, [vp, _i32p, _i32p, _i32p, _i64p, _i32p, _i32p, C.c_int32]),
+        "orc_hnsw_search": (i64, [vp, _f32p, i, _i64p, _f64p, _i32p, C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -186,3 +194,84 @@ class Oracle:
                                    np.ascontiguousarray(g[:, 1]), len(g),
                                    np.ascontiguousarray(p[:, 0], dtype=np.int32),
                                    np.ascontiguousarray(p[:, 1]), len(p))
+
+
+class IvfIndex:
+    """pgvector's IVFFlat restated (vsr_index_oracle.c): k-means on a sample, every row in its nearest list, probes."""
+
+    def __init__(self, oracle, metric, rows, lists=100, seed=1, sample=None):
+        self.orc, self.metric = oracle, metric
+        self.rows = np.ascontiguousarray(rows, dtype=np.float32)
+        n, dim = self.rows.shape
+        self.lists = int(lists)
+        # ivfbuild.c:404-445: max(lists * 50, 10000) sampled rows (all of them when the table is smaller)
+        want = max(self.lists * 50, 10000) if sample is None else int(sample)
+        rng = np.random.default_rng(seed)
+        pick = np.sort(rng.choice(n, size=min(n, want), replace=False)) if n else np.zeros(0, dtype=np.int64)
+        samples = np.ascontiguousarray(self.rows[pick])
+        self.centers = np.zeros((self.lists, dim), dtype=np.float32)
+        rc = oracle.lib.orc_ivf_kmeans(METRICS[metric], dim, samples, len(samples), self.lists, int(seed), self.centers)
+        assert rc == 0
+        self.assign = np.zeros(n, dtype=np.int32)
+        oracle.lib.orc_ivf_assign(METRICS[metric], dim, self.rows, n, self.centers, self.lists, self.assign)
+
+    def probe(self, q, probes):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.zeros(min(probes, self.lists), dtype=np.int32)
+        m = self.orc.lib.orc_ivf_probe(METRICS[self.metric], self.rows.shape[1], self.centers, self.lists, q, int(probes), out)
+        return out[:m]
+
+    def search(self, q, k, probes, row_doc=None, row_block=None, mask=None):
+        """ivfscan.c:112-176 + the executor's filter: the k nearest permitted rows among the probed lists."""
+        lists = self.probe(q, probes)
+        m = np.isin(self.assign, lists).astype(np.uint8)
+        if mask is not None:
+            m &= np.asarray(mask, dtype=np.uint8)
+        return self.orc.filtered_topk(self.metric, self.rows, q, k, row_doc, row_block, m)
+
+
+class HnswIndex:
+    """pgvector's HNSW restated (vsr_index_oracle.c): serial in-memory build, GetScanItems search."""
+
+    def __init__(self, oracle, metric, rows, m=16, ef_construction=64, seed=1):
+        self.orc, self.metric, self.m = oracle, metric, int(m)
+        self.rows = np.ascontiguousarray(rows, dtype=np.float32)
+        n, dim = self.rows.shape
+        self._h = oracle.lib.orc_hnsw_build(METRICS[metric], self.rows, n, dim, int(m), int(ef_construction), int(seed))
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        oracle.lib.orc_hnsw_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        self.n_elem, self.entry, self.entry_level, self.n_upper = a.value, b.value, c.value, d.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.orc.lib.orc_hnsw_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def search(self, q, ef):
+        """Rows in the order hnswgettuple would emit their TIDs, index distances (float8), elements, visited count."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        rows = np.zeros(ef * 10 + 10, dtype=np.int64)
+        dist = np.zeros(ef * 10 + 10, dtype=np.float64)
+        elems = np.zeros(ef + 2, dtype=np.int32)
+        nv = C.c_int64()
+        n = self.orc.lib.orc_hnsw_search(self._h, q, int(ef), rows, dist, elems, C.byref(nv))
+        return rows[:n], dist[:n], elems, nv.value
+
+    def export(self):
+        """Flat arrays for the GPU graph search: level, nbr0 [n_elem][2m], tid_count, tids [n_elem][10], up_slot,
+        up_nbr [n_upper][max_level][m], max_level."""
+        ne, m = self.n_elem, self.m
+        max_level = max(self.entry_level, 1)
+        level = np.zeros(ne, dtype=np.int32)
+        nbr0 = np.zeros((ne, 2 * m), dtype=np.int32)
+        tid_count = np.zeros(ne, dtype=np.int32)
+        tids = np.zeros((ne, 10), dtype=np.int64)
+        up_slot = np.zeros(ne, dtype=np.int32)
+        up_nbr = np.zeros((max(self.n_upper, 1), max_level, m), dtype=np.int32)
+        self.orc.lib.orc_hnsw_export(self._h, level, nbr0.reshape(-1), tid_count, tids.reshape(-1), up_slot,
+                                     up_nbr.reshape(-1), max_level)
+        return {"level": level, "nbr0": nbr0, "tid_count": tid_count, "tids": tids, "up_slot": up_slot, "up_nbr": up_nbr,
+                "max_level": max_level, "entry": self.entry, "m": m}

@@ -110,4 +110,17 @@ void orc_search_ranges(int metric, const float *rows, int64_t n_rows, int dim,
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- index paths (vsr_index_oracle.c): pgvector's IVFFlat and HNSW restated ---------------------------------------- */
+int     orc_ivf_kmeans(int metric, int dim, const float *samples, int64_t ns, int lists, uint64_t seed, float *centers);
+void    orc_ivf_assign(int metric, int dim, const float *rows, int64_t n, const float *centers, int lists, int32_t *assign);
+int     orc_ivf_probe(int metric, int dim, const float *centers, int lists, const float *q, int probes, int32_t *out_lists);
+void   *orc_hnsw_build(int metric, const float *rows, int64_t n, int dim, int m, int ef_construction, uint64_t seed);
+void    orc_hnsw_free(void *h);
+void    orc_hnsw_info(const void *h, int32_t *n_elem, int32_t *entry, int32_t *entry_level, int32_t *n_upper);
+void    orc_hnsw_export(const void *h, int32_t *level, int32_t *nbr0, int32_t *tid_count, int64_t *tids, int32_t *up_slot,
+                        int32_t *up_nbr, int32_t max_level);
+int64_t orc_hnsw_search(const void *h, const float *q, int ef, int64_t *out_rows, double *out_dist, int32_t *out_elems,
+                        int64_t *n_visited);
+
 #endif
