@@ -174,6 +174,22 @@ int vsr_merge_topk_packed_device(vsr_ctx* ctx, const void* d_packed, int n_parts
 int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, const float* b, int64_t n_pairs,
                        int dim_a, int dim_b, int b_broadcast, double* out);
 
+/* ---- IVFFlat list probe (pgvector/src/ivfscan.c:36-176, 339-389) ------------------------------------------ */
+/* An index = `lists` centres (lists x dim floats) and the list of every corpus row (row_list[n], caller row order): what
+ * IVFFlat's build leaves in its list pages (ivfbuild.c, ivfkmeans.c).  The library keeps a list-ordered image of the rows
+ * beside the corpus, so that a probe reads contiguous memory.  vsr_ivf_search = ivfflatgettuple's first call + the
+ * executor's LIMIT and RLS filter: the `probes` nearest lists of each query (GetScanLists; equal centre distances: the
+ * lower list first) are scanned exhaustively (GetScanItems) and the k nearest PERMITTED rows come back, same output
+ * conventions as vsr_search.  Metric L2 / IP / COSINE as the opclasses define them (cosine: pass unit queries; the
+ * centres are unit vectors; rows rank by negative inner product inside the lists and report the operator's value). */
+typedef struct vsr_ivf vsr_ivf;
+int vsr_ivf_load(vsr_corpus* corpus, const float* centers, int lists, const int32_t* row_list, vsr_ivf** out);
+int vsr_ivf_free(vsr_ivf* ivf);       /* before vsr_corpus_free of its corpus */
+int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim, int probes, int metric, int32_t* out_lists /* nq*probes */);
+int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, int probes, int metric,
+                   const vsr_filter* const* filters,
+                   int64_t* out_block_ids, int32_t* out_doc_ids, int64_t* out_rows, float* out_dist, int32_t* out_counts);
+
 /* opclass support functions for n vectors at once (host pointers): vector_norm (vector.c:756-769), l2_normalize
  * (vector.c:774-808; fails with "value out of range: overflow" like float_overflow_error) and
  * vector_spherical_distance (vector.c:692-711; unit vectors assumed, as IVFFlat's spherical k-means uses it) */

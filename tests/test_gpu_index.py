@@ -1,0 +1,99 @@
+"""GPU index paths against the index oracle (oracle/vsr_index_oracle.c = pgvector's IVFFlat / HNSW restated).
+
+K3 (IVFFlat list probe): given the oracle's centres and list assignment, the GPU must probe exactly the oracle's lists
+(GetScanLists, ivfscan.c:36-107) and return exactly the oracle's rows for probes in {1, 5, lists}, unfiltered and under
+RBAC filters (the executor's filter above the index scan).  Integer-valued rows: fp32 sums are exact, so ids and
+distances are compared bit for bit."""
+import numpy as np
+import pytest
+
+from oracle.oracle import IvfIndex as OracleIvf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vsrbac
+    c = vsrbac.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def sift60k(oracle):
+    rng = np.random.default_rng(61)
+    n, dim = 60_000, 128
+    x = np.clip(np.rint(np.abs(rng.normal(0, 45, (n, dim)))), 0, 255).astype(np.float32)
+    blk = (np.arange(n) + 1).astype(np.int64)
+    doc = (np.arange(n) // 20 + 1).astype(np.int32)
+    ivf = OracleIvf(oracle, "l2", x, lists=50, seed=9)
+    return x, blk, doc, ivf
+
+
+@pytest.mark.parametrize("nq", [3, 40])
+def test_ivf_probe_and_search_match_the_oracle(ctx, oracle, sift60k, nq):
+    import vsrbac
+    x, blk, doc, oivf = sift60k
+    n = len(x)
+    rng = np.random.default_rng(62 + nq)
+    corpus = ctx.load_corpus(x, blk, doc)
+    ndocs = int(doc.max())
+    perms = [(1, int(d)) for d in rng.choice(np.arange(1, ndocs + 1), ndocs // 3, replace=False)] + \
+            [(2, int(d)) for d in rng.choice(np.arange(1, ndocs + 1), ndocs // 10, replace=False)]
+    ur = [(u, 1 + u % 2) for u in range(1, 7)] + [(6, 1)]
+    corpus.load_rbac(ur, perms)
+    gpu = corpus.load_ivf(oivf.centers, oivf.assign)
+    q = x[rng.integers(0, n, nq)] + rng.integers(-2, 3, (nq, x.shape[1])).astype(np.float32)
+    users = rng.integers(1, 7, nq)
+    masks = [oracle.user_row_mask(int(u), ur, perms, doc) for u in users]
+    for probes in (1, 5, 50):
+        got_lists = gpu.probe(q, probes)
+        for i in range(nq):
+            assert got_lists[i].tolist() == oivf.probe(q[i], probes).tolist(), (probes, i)
+        for kind in ("none", "ranges", "bitmap"):
+            if kind == "none":
+                filters, ms = None, [None] * nq
+            else:
+                mode = vsrbac.RANGES if kind == "ranges" else vsrbac.BITMAP
+                filters, ms = [corpus.filter_for_user(int(u), mode) for u in users], masks
+            res = gpu.search(q, 100, probes, "l2", filters)
+            for i in range(0, nq, max(1, nq // 8)):
+                idx, dist = oivf.search(q[i], 100, probes, doc, blk, ms[i])
+                m = res.counts[i]
+                assert m == idx.size, (probes, kind, i, m, idx.size)
+                np.testing.assert_array_equal(res.rows[i, :m], idx)
+                np.testing.assert_array_equal(res.dist[i, :m], dist.astype(np.float32))
+                assert (res.block_ids[i, m:] == -1).all()
+    # probes = lists is the exact scan of the corpus
+    full = corpus.search(q, 100, "l2")
+    np.testing.assert_array_equal(gpu.search(q, 100, 50, "l2").rows, full.rows)
+    gpu.free()
+    corpus.free()
+
+
+def test_ivf_cosine_opclass_on_unit_rows(ctx, oracle):
+    """vector_cosine_ops: spherical k-means centres, probe by negative inner product, rows are unit vectors."""
+    rng = np.random.default_rng(71)
+    n, dim = 30_000, 96
+    x = rng.normal(size=(n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    oivf = OracleIvf(oracle, "cosine", x, lists=30, seed=2)
+    corpus = ctx.load_corpus(x)
+    gpu = corpus.load_ivf(oivf.centers, oivf.assign)
+    q = x[rng.integers(0, n, 20)] + 0.05 * rng.normal(size=(20, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    got_lists = gpu.probe(q, 4, "cosine")
+    res = gpu.search(q, 50, 4, "cosine")
+    agree = 0
+    for i in range(20):
+        want_lists = oivf.probe(q[i], 4)
+        agree += got_lists[i].tolist() == want_lists.tolist()
+        if got_lists[i].tolist() != want_lists.tolist():
+            continue                                  # a centre-distance near-tie resolved the other way: different lists
+        idx, dist = oivf.search(q[i], 50, 4)
+        assert len(set(res.rows[i].tolist()) & set(idx.tolist())) >= 49
+        np.testing.assert_allclose(res.dist[i], dist, rtol=1e-4, atol=1e-4)
+    assert agree >= 19
+    gpu.free()
+    corpus.free()

@@ -85,6 +85,8 @@ struct ScanParams {
     uint64_t*        qcand;        // [n_slots][capq]
     uint32_t*        qcnt;         // [n_slots]
     uint32_t         capq;
+    const uint32_t*  rank;         // physical row -> row of the (document_id, block_id) order that keys carry; nullptr:
+                                   // identity.  Set for list-ordered views (IVF): see vsr_corpus::base
     const uint64_t*  ones;         // one all-ones 64-bit word (the "bitmap" of passes without a permission bitmap)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
 };
@@ -268,6 +270,12 @@ hipError_t launch_pack_bytemask(const uint8_t* mask_by_orig_row, const int64_t* 
                                 uint64_t* bitmap, hipStream_t s);
 hipError_t launch_pair_distances(const float* a, const float* b, int64_t n_pairs, int dim, int b_broadcast,
                                  int metric, double* out, hipStream_t s);
+hipError_t launch_gather_rows(const float4* src, const float* src_norm, const uint32_t* rank, uint32_t n_rows, uint32_t stride4,
+                              float4* dst, float* dst_norm, hipStream_t s);
+hipError_t launch_view_bitmap(const uint32_t* rank, uint32_t n_rows, const uint2* tiles, uint32_t n_tiles, const uint64_t* bitmap,
+                              uint64_t* out, hipStream_t s);
+hipError_t launch_ivf_probe(const float* queries, uint32_t nq, const float* centers, int dim, int lists, int probes, int metric,
+                            int32_t* out, hipStream_t s);
 hipError_t launch_vector_fn(int mode, const float* a, const float* b, int64_t n, int dim, int b_broadcast, double* out_d,
                             float* out_f, int* overflow, hipStream_t s);
 hipError_t launch_merge_lists(const uint64_t* keys, const int64_t* blocks, const int32_t* docs, const float* dist,

@@ -1007,6 +1007,119 @@ hipError_t launch_seed_select(const uint64_t* samp, const uint32_t* samp_cnt, ui
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------------------------------------
+// K3 support: list-ordered view of a corpus (IVFFlat).  Rows of a list are contiguous in the view; `rank[p]` is the row
+// of the (document_id, block_id) order that physical row p holds, which is what ordering keys carry.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float4* src, const float* src_norm, const uint32_t* rank,
+                                                          uint32_t n_rows, uint32_t stride4, float4* dst, float* dst_norm)
+{
+    const uint64_t total = (uint64_t) n_rows * stride4;
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t) gridDim.x * 256) {
+        const uint32_t p = (uint32_t) (i / stride4), c = (uint32_t) (i % stride4);
+        const uint32_t r = rank[p];
+        dst[i] = src[(size_t) r * stride4 + c];
+        if (c == 0) dst_norm[p] = src_norm[r];
+    }
+}
+
+hipError_t launch_gather_rows(const float4* src, const float* src_norm, const uint32_t* rank, uint32_t n_rows, uint32_t stride4,
+                              float4* dst, float* dst_norm, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t total = (uint64_t) n_rows * stride4;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t) std::min<uint64_t>((total + 255) / 256, 16384)), dim3(256), 0, s, src,
+                       src_norm, rank, n_rows, stride4, dst, dst_norm);
+    return hipGetLastError();
+}
+
+// a filter of the base corpus as a per-row bitmap in view order: bit(p) = base row rank[p] lies in one of the filter's
+// tiles (sorted by start) and, when the filter carries a bitmap, has its bit set
+__global__ __launch_bounds__(256) void view_bitmap_kernel(const uint32_t* rank, uint32_t n_rows, const uint2* tiles,
+                                                          uint32_t n_tiles, const uint64_t* bitmap, uint64_t* out)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    bool ok = p < n_rows;
+    if (ok) {
+        const uint32_t r = rank[p];
+        if (tiles) {
+            uint32_t lo = 0, hi = n_tiles;                   // last tile with start <= r
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (tiles[mid].x <= r) lo = mid; else hi = mid;
+            }
+            ok = n_tiles > 0 && tiles[lo].x <= r && r - tiles[lo].x < tiles[lo].y;
+        }
+        if (ok && bitmap) ok = (bitmap[r >> 6] >> (r & 63)) & 1ull;
+    }
+    const uint64_t bits = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && p < n_rows) out[p >> 6] = bits;
+}
+
+hipError_t launch_view_bitmap(const uint32_t* rank, uint32_t n_rows, const uint2* tiles, uint32_t n_tiles, const uint64_t* bitmap,
+                              uint64_t* out, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(view_bitmap_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, rank, n_rows, tiles, n_tiles, bitmap, out);
+    return hipGetLastError();
+}
+
+// GetScanLists (ivfscan.c:36-107): per query the `probes` nearest of `lists` centres under the opclass distance (L2
+// squared, or negative inner product), nearest first, the lower list id first among equals.  One workgroup per query.
+// The sums run in the order and rounding of vector.c's loops compiled without contraction (one lane per centre).
+__global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, const float* centers, int dim, int lists, int probes,
+                                                        int metric, int32_t* out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);     // [lists]
+    __shared__ uint64_t s_best[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* q = queries + (size_t) blockIdx.x * dim;
+    for (int c = tid; c < lists; c += 256) {
+        const float* x = centers + (size_t) c * dim;
+        float sum = 0.0f;
+        if (metric == M_L2) {
+            for (int j = 0; j < dim; ++j) {
+                const float d = __fsub_rn(x[j], q[j]);
+                sum = __fadd_rn(sum, __fmul_rn(d, d));
+            }
+        } else {
+            for (int j = 0; j < dim; ++j) sum = __fadd_rn(sum, __fmul_rn(x[j], q[j]));
+            sum = -sum;
+        }
+        keys[c] = make_key(sum, (uint32_t) c);
+    }
+    __syncthreads();
+    for (int pr = 0; pr < probes; ++pr) {
+        uint64_t best = KEY_EMPTY;
+        for (int c = tid; c < lists; c += 256) best = keys[c] < best ? keys[c] : best;
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) best, m), hi = (uint32_t) __shfl_xor((int) (uint32_t) (best >> 32), m);
+            const uint64_t o = ((uint64_t) hi << 32) | lo;
+            best = o < best ? o : best;
+        }
+        if (lane == 0) s_best[wave] = best;
+        __syncthreads();
+        uint64_t b = s_best[0];
+        for (int w = 1; w < 4; ++w) b = s_best[w] < b ? s_best[w] : b;
+        if (tid == 0) {
+            out[(size_t) blockIdx.x * probes + pr] = b == KEY_EMPTY ? -1 : (int32_t) (uint32_t) b;
+            if (b != KEY_EMPTY) keys[(uint32_t) b] = KEY_EMPTY;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_ivf_probe(const float* queries, uint32_t nq, const float* centers, int dim, int lists, int probes, int metric,
+                            int32_t* out, hipStream_t s)
+{
+    if (nq == 0) return hipSuccess;
+    const size_t lds = (size_t) lists * sizeof(uint64_t);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivf_probe_kernel, dim3(nq), dim3(256), lds, s, queries, centers, dim, lists, probes, metric, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s)
 {
     uint32_t np2 = 2;

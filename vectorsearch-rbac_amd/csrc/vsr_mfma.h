@@ -70,6 +70,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
     const uint32_t local_block = p.block_map ? mapped_block : blockIdx.x - grp.block_begin;
     const auto g_tiles = as_global(grp.tiles);                                 // global_load, not flat (vsr_device.h)
     const auto g_bitmap = as_global(grp.bitmap);
+    const auto g_rank = as_global(p.rank);
 
     const uint32_t stride4 = p.stride4, cap = p.cap, keep = p.k;
     const uint32_t nstage = (stride4 + MF_S - 1) / MF_S;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mfma_scan_kernel(const ScanPara
                     for (int i = 0; i < 16; ++i)
                         if (pmask & (1u << i)) {                               // the key is built for survivors only
                             const int32_t row = ridx[(i >> 2) * 16 + kq * 4 + (i & 3)];
-                            dst[__popc(pmask & ((1u << i) - 1u))] = make_key(vv[i], (uint32_t) row);
+                            dst[__popc(pmask & ((1u << i) - 1u))] = make_key(vv[i], g_rank ? g_rank[row] : (uint32_t) row);
                         }
                 }
             }

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     const auto g_bitmap = as_global(grp.bitmap);
     const auto g_norm2 = as_global(p.norm2);
     const auto g_ones = as_global(p.ones);
+    const auto g_rank = as_global(p.rank);
 
     const uint32_t pstride4 = p.pstride4;
     const uint32_t q_count = grp.q_count;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
                                 const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
                                 const uint32_t at = base + (uint32_t) __popc(pmask & ((1u << j) - 1u));
                                 const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
-                                if (at < p.capq) my_cand[at] = make_key(v, (uint32_t) ridx[slot]);
+                                if (at < p.capq) my_cand[at] = make_key(v, g_rank ? g_rank[ridx[slot]] : (uint32_t) ridx[slot]);
                             }
                     }
                 }

@@ -53,6 +53,7 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
     const uint32_t q_count = grp.q_count;
     const auto g_tiles = as_global(grp.tiles);                                 // global_load, not flat (vsr_device.h)
     const auto g_bitmap = as_global(grp.bitmap);
+    const auto g_rank = as_global(p.rank);
 
     float4*   stage = reinterpret_cast<float4*>(smem) + (size_t) wave * 64 * MQ_PITCH;
     int32_t*  rowidx = reinterpret_cast<int32_t*>(smem + (size_t) MQ_WAVES * 64 * MQ_PITCH * 16) + wave * 64;
@@ -166,7 +167,7 @@ __device__ __forceinline__ void mq_body(const ScanParams& p, const ScanGroup& gr
             for (int q = 0; q < NQ; ++q) {
                 if ((uint32_t) q < q_count) {                                  // workgroup-uniform
                     const float v = rank_value<METRIC>(acc[q], rn, qnl[q]);
-                    const uint64_t key = make_key(v, (uint32_t) myrow);
+                    const uint64_t key = make_key(v, g_rank && valid ? g_rank[myrow] : (uint32_t) myrow);
                     const uint64_t tau = lds_peek(&ctrl[q].tau);
                     topk_append(cand + (size_t) q * cand_qstride, &ctrl[q], valid && key < tau, key);
                 }

@@ -192,6 +192,7 @@ struct vsr_filter {
     // pre-filter of a role set = union of disjoint permission classes (documents with the same role signature);
     // the planner scans class by class so that queries of different roles share the classes they have in common
     std::vector<vsr_filter*> parts;
+    bool parts_only = false;               // the filter has no tile list of its own: always scanned part by part (IVF probes)
     // planner scratch (one planner per context at a time): group id of this filter in the plan being built
     mutable uint64_t plan_epoch = 0;
     mutable uint32_t plan_group = 0;
@@ -207,6 +208,11 @@ struct vsr_corpus {
     float4*     d_rows = nullptr;
     float*      d_norm2 = nullptr;
     uint4*      d_scr = nullptr;         // K2w screening planes (bf16 hi / mid split of the rows), nullptr: not built
+    // list-ordered VIEW of another corpus (IVFFlat, vsr_ivf_load): rows / norms / planes / tile lists are the view's own,
+    // in list order; identity arrays, RBAC tables and the fp32 rows the exact re-rank gathers stay in `base`, and keys carry
+    // base rows through d_rank (physical row -> base row)
+    vsr_corpus* base = nullptr;
+    uint32_t*   d_rank = nullptr;
     uint2*      d_all_tiles = nullptr;   // identity tile list (K2w always walks an explicit list: unfiltered passes use this)
     uint32_t    pstride4 = 0;            // 16-byte chunks per plane row
     bool        scr_has_mid = true;      // false: every element is exactly a bf16 value (e.g. SIFT's 0..255 integers)
@@ -436,7 +442,7 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
 vsr_corpus::~vsr_corpus()
 {
     drop_cached_filters(this);
-    void* ptrs[] = {d_rows, d_scr, d_all_tiles, d_doc_class, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
+    void* ptrs[] = {d_rows, d_scr, d_all_tiles, d_doc_class, d_rank, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
     for (void* p : ptrs)
         if (p) (void) hipFree(p);
 }
@@ -1100,7 +1106,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     };
     for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
         const vsr_filter* f = fof(q);
-        if (decompose && f && !f->parts.empty()) {
+        if (f && !f->parts.empty() && (decompose || f->parts_only)) {
             for (const vsr_filter* part : f->parts) {
                 const uint32_t g = group_of(part);
                 raw.push_back({part, q});
@@ -1441,6 +1447,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
                        uint64_t* d_keys)
 {
     const uint32_t kp = plan.keep;
+    const vsr_corpus* idc = c->base ? c->base : c;          // identity arrays and re-rank rows (c may be a list-ordered view)
     const size_t qfloats = (size_t) c->stride4 * 4;
     const size_t q_pstride = c->scr_has_mid ? c->pstride4 : 2 * (size_t) c->pstride4;    // query planes keep hi and mid
     // staging block: [queries | q_norm2 | query planes || scan groups | sample groups | pass query slots | per-query items | block map]
@@ -1538,6 +1545,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     sp.rw = (uint32_t) c->shape.rw;
     sp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;
     sp.ones = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ctx->d_flag_total) + 32);
+    sp.rank = c->d_rank;
 
     if (plan.n_blocks) {
         // ---- sample pass: every sample_stride-th tile, open threshold, into the queries' sample buffers ----
@@ -1596,18 +1604,18 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     }
     RerankParams rr{};
     rr.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
-    rr.rows = c->d_rows;
+    rr.rows = idc->d_rows;
     rr.stride4 = c->stride4;
     rr.queries_f = reinterpret_cast<const float*>(ds + off_q);
     rr.kp = kp;
     rr.k = (uint32_t) k;
     rr.metric = metric;
     rr.dim = c->dim;
-    rr.norm2_max = c->d_norm2_max;
-    rr.row_offset = (uint32_t) c->row_offset;
-    rr.block_ids = c->d_block;
-    rr.doc_ids = c->d_doc;
-    rr.orig_rows = c->d_orig;
+    rr.norm2_max = idc->d_norm2_max;
+    rr.row_offset = (uint32_t) idc->row_offset;
+    rr.block_ids = idc->d_block;
+    rr.doc_ids = idc->d_doc;
+    rr.orig_rows = idc->d_orig;
     rr.out_block = d_blk;
     rr.out_doc = d_doc;
     rr.out_row = d_row;
@@ -1665,6 +1673,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     ctx->host_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
 
     const uint32_t kp = plan.keep;
+    const vsr_corpus* idc = c->base ? c->base : c;          // identity arrays and re-rank rows (c may be a list-ordered view)
     const size_t qfloats = (size_t) c->stride4 * 4;
     // one staging block: [queries | q_norm2 | scan groups | sample groups | pass query slots | K5 items | list ids]
     const size_t off_q = 0;
@@ -1754,6 +1763,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     sp.cand = nullptr;
     sp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;    // bounds-guard word (checked by vsr_screening_check)
     sp.ones = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ctx->d_flag_total) + 32);
+    sp.rank = c->d_rank;
     sp.block_map = nullptr;
     if (plan.mq || plan.k2) {
         if ((rc = ctx->d_cand.reserve(std::max<size_t>(8, (size_t) plan.n_scan_lists * cand_pitch(sp.cap) * sizeof(uint64_t))))) return rc;
@@ -1777,10 +1787,10 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     const int sel_threads = plan.sel_wave ? 64 : (uint64_t) max_lists * kp <= 16384 ? 256 : 1024;
     sel.cap = plan.sel_wave ? std::max<uint32_t>(1024, max_lists * kp) : select_cap(kp, sel_threads);   // wave: key capacity
     sel.metric = metric;
-    sel.row_offset = (uint32_t) c->row_offset;
-    sel.block_ids = c->d_block;
-    sel.doc_ids = c->d_doc;
-    sel.orig_rows = c->d_orig;
+    sel.row_offset = (uint32_t) idc->row_offset;
+    sel.block_ids = idc->d_block;
+    sel.doc_ids = idc->d_doc;
+    sel.orig_rows = idc->d_orig;
     sel.out_block = d_blk;
     sel.out_doc = d_doc;
     sel.out_row = d_row;
@@ -1891,18 +1901,18 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         RerankParams rr{};
         rr.lists = ctx->d_partial.as<uint64_t>() + (size_t) plan.rerank_base * kp;
         rr.queries = reinterpret_cast<const SelectQuery*>(ds + off_sq);
-        rr.rows = c->d_rows;
+        rr.rows = idc->d_rows;
         rr.stride4 = c->stride4;
         rr.queries_f = reinterpret_cast<const float*>(ds + off_q);
         rr.kp = kp;
         rr.k = (uint32_t) k;
         rr.metric = metric;
         rr.dim = c->dim;
-        rr.norm2_max = c->d_norm2_max;
-        rr.row_offset = (uint32_t) c->row_offset;
-        rr.block_ids = c->d_block;
-        rr.doc_ids = c->d_doc;
-        rr.orig_rows = c->d_orig;
+        rr.norm2_max = idc->d_norm2_max;
+        rr.row_offset = (uint32_t) idc->row_offset;
+        rr.block_ids = idc->d_block;
+        rr.doc_ids = idc->d_doc;
+        rr.orig_rows = idc->d_orig;
         rr.out_block = d_blk;
         rr.out_doc = d_doc;
         rr.out_row = d_row;
@@ -1969,14 +1979,12 @@ extern "C" int vsr_search_device(vsr_corpus* c, const float* d_queries, int nq, 
                                 d_keys);
 }
 
-extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, int k, int metric,
-                          const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
-                          float* out_dist, int32_t* out_cnt)
+// Host-buffer search on a corpus or on a list-ordered view of one: the search, then the exact re-run of flagged queries.
+static int host_search(vsr_corpus* c, const float* queries, int nq, int dim, int k, int metric,
+                       const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
+                       float* out_dist, int32_t* out_cnt)
 {
-    int rc = check_search_args(c, queries, nq, dim, k, metric, filters, "vsr_search");
-    if (rc) return rc;
-    if (nq == 0) return VSR_OK;
-    if (!out_blk || !out_dist || !out_cnt) return fail(VSR_ERR_INVALID, "vsr_search: output is NULL");
+    int rc;
     vsr_ctx* ctx = c->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nk = (size_t) nq * k;
@@ -2028,6 +2036,18 @@ extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, 
         }
     }
     return VSR_OK;
+}
+
+extern "C" int vsr_search(vsr_corpus* c, const float* queries, int nq, int dim, int k, int metric,
+                          const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
+                          float* out_dist, int32_t* out_cnt)
+{
+    int rc = check_search_args(c, queries, nq, dim, k, metric, filters, "vsr_search");
+    if (rc) return rc;
+    if (c->base) return fail(VSR_ERR_INVALID, "vsr_search: this corpus is an index view; use the index's search function");
+    if (nq == 0) return VSR_OK;
+    if (!out_blk || !out_dist || !out_cnt) return fail(VSR_ERR_INVALID, "vsr_search: output is NULL");
+    return host_search(c, queries, nq, dim, k, metric, filters, out_blk, out_doc, out_row, out_dist, out_cnt);
 }
 
 extern "C" int vsr_last_scan_kernel(vsr_ctx* ctx, char* name, int name_len)
@@ -2172,4 +2192,222 @@ extern "C" int vsr_spherical_distances(vsr_ctx* ctx, const float* a, const float
                                        int b_broadcast, double* out)
 {
     return vector_fn(ctx, 2, a, b, n, dim_a, dim_b, b_broadcast, out, nullptr, "vsr_spherical_distances");
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: IVFFlat list probe (ivfscan.c:36-176, 339-389) over a list-ordered view of the corpus
+// ---------------------------------------------------------------------------------------------
+struct vsr_ivf {
+    vsr_corpus* main = nullptr;
+    vsr_corpus* view = nullptr;                      // list-ordered rows; view->base = main
+    int         lists = 0;
+    float*      d_centers = nullptr;
+    std::vector<uint32_t> list_start;                // lists + 1 offsets into the view
+    std::vector<vsr_filter*> list_filters;           // one RANGES filter per list (tiles over the view)
+    struct ViewBitmap { uint64_t* d = nullptr; std::vector<uint64_t> h; };
+    std::map<const vsr_filter*, ViewBitmap> view_bitmaps;                 // a base filter as a bitmap in view order
+    std::map<std::pair<const vsr_filter*, int>, vsr_filter*> parts;       // (base filter, list) -> part of a probe
+    DevBuf d_q, d_probe;
+};
+
+extern "C" int vsr_ivf_free(vsr_ivf* ivf)
+{
+    if (!ivf) return VSR_OK;
+    if (ivf->main) {
+        (void) hipSetDevice(ivf->main->ctx->device);
+        (void) hipStreamSynchronize(ivf->main->ctx->stream);
+    }
+    for (auto& kv : ivf->parts) delete kv.second;    // tiles / bitmaps are borrowed
+    for (auto& kv : ivf->view_bitmaps)
+        if (kv.second.d) (void) hipFree(kv.second.d);
+    for (vsr_filter* f : ivf->list_filters) free_filter(f);
+    if (ivf->d_centers) (void) hipFree(ivf->d_centers);
+    ivf->d_q.release();
+    ivf->d_probe.release();
+    delete ivf->view;                                // frees the view's own arrays only
+    delete ivf;
+    return VSR_OK;
+}
+
+extern "C" int vsr_ivf_load(vsr_corpus* c, const float* centers, int lists, const int32_t* row_list, vsr_ivf** out)
+{
+    if (!c || !out || !centers || (c->n > 0 && !row_list)) return fail(VSR_ERR_INVALID, "vsr_ivf_load: NULL argument");
+    *out = nullptr;
+    if (c->base) return fail(VSR_ERR_INVALID, "vsr_ivf_load: the corpus is itself a view");
+    if (lists < 1 || lists > 8192) return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_load: lists must be between 1 and 8192 (got %d)", lists);
+    vsr_ctx* ctx = c->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = c->n;
+    for (int64_t i = 0; i < n; ++i)
+        if (row_list[i] < 0 || row_list[i] >= lists) return fail(VSR_ERR_INVALID, "vsr_ivf_load: row %lld has list %d", (long long) i, row_list[i]);
+    std::unique_ptr<vsr_ivf> ivf(new vsr_ivf());
+    ivf->main = c;
+    ivf->lists = lists;
+    // view order: by list, then by base row (= (document_id, block_id) order inside a list)
+    std::vector<uint32_t> count((size_t) lists + 1, 0);
+    for (int64_t r = 0; r < n; ++r) count[(size_t) row_list[c->h_orig[(size_t) r]] + 1]++;
+    for (int l = 0; l < lists; ++l) count[(size_t) l + 1] += count[(size_t) l];
+    ivf->list_start = count;
+    std::vector<uint32_t> rank((size_t) std::max<int64_t>(n, 1));
+    {
+        std::vector<uint32_t> cur(count.begin(), count.end() - 1);
+        for (int64_t r = 0; r < n; ++r) rank[cur[(size_t) row_list[c->h_orig[(size_t) r]]]++] = (uint32_t) r;
+    }
+    std::unique_ptr<vsr_corpus> v(new vsr_corpus());
+    v->ctx = ctx;
+    v->n = n;
+    v->dim = c->dim;
+    v->stride4 = c->stride4;
+    v->row_offset = c->row_offset;
+    v->shape = c->shape;
+    v->base = c;
+    v->k2_safe = c->k2_safe;
+    const size_t alloc_rows = (size_t) std::max<int64_t>(n, 1), row_bytes = (size_t) c->stride4 * 16;
+    HIPCHK(hipMalloc(&v->d_rank, alloc_rows * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(v->d_rank, rank.data(), alloc_rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&v->d_rows, alloc_rows * row_bytes + 1024));
+    HIPCHK(hipMalloc(&v->d_norm2, alloc_rows * sizeof(float)));
+    HIPCHK(launch_gather_rows(c->d_rows, c->d_norm2, v->d_rank, (uint32_t) n, c->stride4, v->d_rows, v->d_norm2, ctx->stream));
+    if (c->d_scr) {                                  // the view's own screening planes, in its order
+        v->scr_has_mid = c->scr_has_mid;
+        v->pstride4 = c->pstride4;
+        HIPCHK(hipMalloc(&v->d_scr, alloc_rows * (size_t) v->pstride4 * 16 + 1024));
+        HIPCHK(launch_split_planes(v->d_rows, (uint32_t) n, v->stride4, v->d_scr, v->pstride4, !v->scr_has_mid, ctx->stream));
+        std::vector<uint2> all;
+        ranges_to_tiles({{0u, (uint32_t) n}}, v->shape.rw, all);
+        HIPCHK(hipMalloc(&v->d_all_tiles, std::max<size_t>(8, all.size() * sizeof(uint2))));
+        if (!all.empty()) HIPCHK(hipMemcpy(v->d_all_tiles, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc(&ivf->d_centers, (size_t) lists * c->dim * sizeof(float)));
+    HIPCHK(hipMemcpy(ivf->d_centers, centers, (size_t) lists * c->dim * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ivf->view = v.release();
+    ivf->list_filters.assign((size_t) lists, nullptr);
+    for (int l = 0; l < lists; ++l) {
+        std::unique_ptr<vsr_filter, void (*)(vsr_filter*)> f(new vsr_filter(), free_filter);
+        f->corpus = ivf->view;
+        f->mode = VSR_FILTER_RANGES;
+        f->cached = true;
+        std::vector<uint2> tiles;
+        const uint32_t s0 = ivf->list_start[(size_t) l], s1 = ivf->list_start[(size_t) l + 1];
+        if (s1 > s0) ranges_to_tiles({{s0, s1}}, ivf->view->shape.rw, tiles);
+        int rc = upload_tiles(f.get(), tiles);
+        if (rc) { vsr_ivf_free(ivf.release()); return rc; }
+        f->allowed_rows = f->scanned_rows = s1 - s0;
+        ivf->list_filters[(size_t) l] = f.release();
+    }
+    *out = ivf.release();
+    return VSR_OK;
+}
+
+// (base filter, list) as a filter of the view: the list's tiles and the base filter's bitmap in view order
+static int ivf_part(vsr_ivf* ivf, const vsr_filter* bf, int list, vsr_filter** out)
+{
+    if (!bf) {
+        *out = ivf->list_filters[(size_t) list];
+        return VSR_OK;
+    }
+    auto key = std::make_pair(bf, list);
+    auto it = ivf->parts.find(key);
+    if (it != ivf->parts.end()) {
+        *out = it->second;
+        return VSR_OK;
+    }
+    vsr_corpus* v = ivf->view;
+    vsr_ctx* ctx = v->ctx;
+    auto& vb = ivf->view_bitmaps[bf];
+    if (!vb.d) {
+        const size_t words = bitmap_words(v->n);
+        HIPCHK(hipMalloc(&vb.d, words * sizeof(uint64_t)));
+        HIPCHK(hipMemsetAsync(vb.d, 0, words * sizeof(uint64_t), ctx->stream));
+        HIPCHK(launch_view_bitmap(v->d_rank, (uint32_t) v->n, bf->d_tiles, bf->n_tiles, bf->d_bitmap, vb.d, ctx->stream));
+        vb.h.resize(words);
+        HIPCHK(hipMemcpyAsync(vb.h.data(), vb.d, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    const vsr_filter* lf = ivf->list_filters[(size_t) list];
+    std::unique_ptr<vsr_filter> f(new vsr_filter());
+    f->corpus = v;
+    f->mode = VSR_FILTER_BITMAP;
+    f->cached = true;
+    f->d_tiles = lf->d_tiles;
+    f->n_tiles = lf->n_tiles;
+    f->d_bitmap = vb.d;
+    f->owns_bitmap = false;
+    f->scanned_rows = lf->scanned_rows;
+    int64_t allowed = 0;
+    for (uint32_t p = ivf->list_start[(size_t) list]; p < ivf->list_start[(size_t) list + 1]; ++p)
+        allowed += (vb.h[p >> 6] >> (p & 63)) & 1ull;
+    f->allowed_rows = allowed;
+    *out = ivf->parts[key] = f.release();
+    return VSR_OK;
+}
+
+extern "C" int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, int probes, int metric,
+                              const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
+                              float* out_dist, int32_t* out_cnt)
+{
+    if (!ivf) return fail(VSR_ERR_INVALID, "vsr_ivf_search: index is NULL");
+    vsr_corpus* main = ivf->main;
+    int rc = check_search_args(main, queries, nq, dim, k, metric, filters, "vsr_ivf_search");
+    if (rc) return rc;
+    if (metric == VSR_METRIC_L1) return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_search: ivfflat has no L1 operator class");
+    if (probes < 1) return fail(VSR_ERR_INVALID, "vsr_ivf_search: probes must be >= 1 (got %d)", probes);   /* ivfflat.c:41-45 */
+    if (nq == 0) return VSR_OK;
+    if (!out_blk || !out_dist || !out_cnt) return fail(VSR_ERR_INVALID, "vsr_ivf_search: output is NULL");
+    probes = std::min(probes, ivf->lists);
+    vsr_ctx* ctx = main->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    // GetScanLists: the probes nearest lists of every query (cosine opclass: the caller passes normalised queries and the
+    // index distance is the negative inner product, vector.sql:323-327)
+    if ((rc = ivf->d_q.reserve((size_t) nq * dim * sizeof(float)))) return rc;
+    if ((rc = ivf->d_probe.reserve((size_t) nq * probes * sizeof(int32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(ivf->d_q.p, queries, (size_t) nq * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(launch_ivf_probe(ivf->d_q.as<float>(), (uint32_t) nq, ivf->d_centers, dim, ivf->lists, probes,
+                            metric == VSR_METRIC_L2 ? M_L2 : M_IP, ivf->d_probe.as<int32_t>(), ctx->stream));
+    std::vector<int32_t> probe((size_t) nq * probes);
+    HIPCHK(hipMemcpyAsync(probe.data(), ivf->d_probe.p, probe.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // GetScanItems: every query scans the rows of its lists (and only the permitted ones)
+    std::vector<std::unique_ptr<vsr_filter>> owned((size_t) nq);
+    std::vector<const vsr_filter*> fl((size_t) nq, nullptr);
+    for (int q = 0; q < nq; ++q) {
+        std::unique_ptr<vsr_filter> f(new vsr_filter());
+        f->corpus = ivf->view;
+        f->mode = VSR_FILTER_RANGES;
+        f->parts_only = true;
+        for (int j = 0; j < probes; ++j) {
+            const int32_t l = probe[(size_t) q * probes + j];
+            if (l < 0) continue;
+            vsr_filter* part = nullptr;
+            if ((rc = ivf_part(ivf, filters ? filters[q] : nullptr, l, &part))) return rc;
+            if (part->n_tiles == 0) continue;
+            f->parts.push_back(part);
+            f->allowed_rows += part->allowed_rows;
+            f->scanned_rows += part->scanned_rows;
+        }
+        fl[(size_t) q] = f.get();
+        owned[(size_t) q] = std::move(f);
+    }
+    return host_search(ivf->view, queries, nq, dim, k, metric, fl.data(), out_blk, out_doc, out_row, out_dist, out_cnt);
+}
+
+extern "C" int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim, int probes, int metric, int32_t* out_lists)
+{
+    if (!ivf || !queries || !out_lists || nq < 0) return fail(VSR_ERR_INVALID, "vsr_ivf_probe: NULL argument");
+    if (dim != ivf->main->dim) return fail(VSR_ERR_DIM_MISMATCH, "different vector dimensions %d and %d", ivf->main->dim, dim);
+    if (probes < 1) return fail(VSR_ERR_INVALID, "vsr_ivf_probe: probes must be >= 1 (got %d)", probes);
+    if (nq == 0) return VSR_OK;
+    probes = std::min(probes, ivf->lists);
+    vsr_ctx* ctx = ivf->main->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ivf->d_q.reserve((size_t) nq * dim * sizeof(float)))) return rc;
+    if ((rc = ivf->d_probe.reserve((size_t) nq * probes * sizeof(int32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(ivf->d_q.p, queries, (size_t) nq * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(launch_ivf_probe(ivf->d_q.as<float>(), (uint32_t) nq, ivf->d_centers, dim, ivf->lists, probes,
+                            metric == VSR_METRIC_L2 ? M_L2 : M_IP, ivf->d_probe.as<int32_t>(), ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_lists, ivf->d_probe.p, (size_t) nq * probes * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return VSR_OK;
 }

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
     const ScanGroup grp = p.groups[lo];
     const auto g_tiles = as_global(grp.tiles);                                 // global_load, not flat (vsr_device.h)
     const auto g_bitmap = as_global(grp.bitmap);
+    const auto g_rank = as_global(p.rank);                                     // list-ordered views: keys carry the rank
     const uint32_t local_block = blockIdx.x - grp.block_begin;
     const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
     const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
                         const uint32_t qs = sb * QI + qi;
                         reduce_slots<LPR / 2, R>(acc[qi], lane);
                         const float v = rank_value<METRIC>(acc[qi][0], cur.rn, qnl[qs]);
-                        const uint64_t key = make_key(v, start + row_own);
+                        const uint64_t key = make_key(v, g_rank ? g_rank[start + row_own] : start + row_own);
                         const uint64_t tau = lds_peek(&ctrl[qs].tau);
                         const bool pass = own && ok_own && qs < q_count && key < tau;
                         topk_append(keys + (size_t) qs * cap, &ctrl[qs], pass, key);
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
                 for (int qi = 0; qi < QI; ++qi) {
                     reduce_slots<LPR / 2, R>(acc[qi], lane);
                     const float v = rank_value<METRIC>(acc[qi][0], cur.rn, qnl[qi]);
-                    const uint64_t key = make_key(v, start + row_own);
+                    const uint64_t key = make_key(v, g_rank ? g_rank[start + row_own] : start + row_own);
                     const uint64_t tau = lds_peek(&ctrl[qi].tau);
                     const bool pass = own && ok_own && (uint32_t) qi < q_count && key < tau;
                     topk_append(keys + (size_t) qi * cap, &ctrl[qi], pass, key);

@@ -54,6 +54,10 @@ SYMBOLS = {
     "vsr_packed_result_bytes": (_i64, [_i, _i]),
     "vsr_merge_topk_packed_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "vsr_pair_distances": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "vsr_ivf_load": (_i, [_vp, _vp, _i, _vp, C.POINTER(_vp)]),
+    "vsr_ivf_free": (_i, [_vp]),
+    "vsr_ivf_probe": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vsr_ivf_search": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_vector_norms": (_i, [_vp, _vp, _i64, _i, _vp]),
     "vsr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _vp]),
     "vsr_spherical_distances": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),

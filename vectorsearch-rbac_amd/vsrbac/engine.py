@@ -246,6 +246,11 @@ class Corpus:
         check(self._lib.vsr_filter_from_documents(self._h, _ptr(d), d.size, int(user_id), C.byref(h)))
         return Filter(self, h, owned=True)
 
+    # ---- indexes -----------------------------------------------------------------------------
+    def load_ivf(self, centers, row_list):
+        """IVFFlat index over this corpus: centres [lists, dim] and the list of every row (caller row order)."""
+        return IvfIndex(self, centers, row_list)
+
     # ---- search ------------------------------------------------------------------------------
     def pack_filters(self, filters):
         """One filter per query as a reusable C array (build it once when the same batch shape repeats)."""
@@ -292,3 +297,51 @@ class Corpus:
                                              self.dim if dim is None else dim, int(k), _metric(metric), farr, d_block,
                                              d_doc, d_rows, d_dist, d_counts, d_keys))
         return keep
+
+
+class IvfIndex:
+    """pgvector's ivfflat scan (ivfscan.c) on the GPU: probe the nearest lists, scan them, keep the permitted top-k."""
+
+    def __init__(self, corpus, centers, row_list):
+        self.corpus, self._lib = corpus, corpus._lib
+        c = np.ascontiguousarray(centers, dtype=np.float32)
+        rl = np.ascontiguousarray(row_list, dtype=np.int32)
+        if c.ndim != 2 or c.shape[1] != corpus.dim or rl.size != corpus.n:
+            raise ValueError("centers must be [lists, dim] and row_list must have one entry per row")
+        h = C.c_void_p()
+        check(self._lib.vsr_ivf_load(corpus._h, _ptr(c), c.shape[0], _ptr(rl), C.byref(h)))
+        self._h, self.lists = h, c.shape[0]
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.vsr_ivf_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self.corpus._h:
+                self.free()
+        except Exception:
+            pass
+
+    def probe(self, queries, probes, metric="l2"):
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries, dtype=np.float32)))
+        p = min(int(probes), self.lists)
+        out = np.zeros((q.shape[0], p), dtype=np.int32)
+        check(self._lib.vsr_ivf_probe(self._h, _ptr(q), q.shape[0], q.shape[1], int(probes), _metric(metric), _ptr(out)))
+        return out
+
+    def search(self, queries, k, probes, metric="l2", filters=None):
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries, dtype=np.float32)))
+        nq, dim = q.shape
+        farr, keep = self.corpus._filter_array(filters, nq)
+        kk = max(int(k), 1)
+        blk = np.full((nq, kk), -1, dtype=np.int64)
+        doc = np.full((nq, kk), -1, dtype=np.int32)
+        row = np.full((nq, kk), -1, dtype=np.int64)
+        dist = np.full((nq, kk), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.int32)
+        check(self._lib.vsr_ivf_search(self._h, _ptr(q), nq, dim, int(k), int(probes), _metric(metric), farr, _ptr(blk),
+                                       _ptr(doc), _ptr(row), _ptr(dist), _ptr(cnt)))
+        del keep
+        return SearchResult(blk, doc, row, dist, cnt)
