@@ -190,6 +190,25 @@ int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, i
                    const vsr_filter* const* filters,
                    int64_t* out_block_ids, int32_t* out_doc_ids, int64_t* out_rows, float* out_dist, int32_t* out_counts);
 
+/* ---- HNSW graph search (pgvector/src/hnswscan.c:15-45,179-316; hnswutils.c:813-976) -------------------------- */
+/* A graph as pgvector's in-memory build leaves it (hnswbuild.c:357-470): n_elem elements, each with a top level, up to 10
+ * heap TIDs (tids: caller row indices, -1 padded; identical vectors share an element), 2m neighbours on layer 0
+ * (nbr0[n_elem][2m], -1 padded) and m per upper layer (up_nbr[n_upper][max_level][m] for the elements with level >= 1,
+ * addressed through up_slot[n_elem]).  vsr_hnsw_search = hnswgettuple's first call + the executor's filter and LIMIT:
+ * greedy descent (ef = 1) from `entry`, HnswSearchLayer with ef_search on layer 0, then the TIDs of the result elements
+ * nearest first, the permission test per row and the first k.  Equal distances are ordered by element id.  Like the
+ * reference with hnsw.iterative_scan = off, a filtered query can return fewer than k rows.
+ * out_visited (may be NULL): elements entered into the visited set by the layer-0 search, per query. */
+typedef struct vsr_hnsw vsr_hnsw;
+int vsr_hnsw_load(vsr_corpus* corpus, int m, int32_t n_elem, int32_t entry, const int32_t* level, const int32_t* nbr0,
+                  const int32_t* tid_count, const int64_t* tids, const int32_t* up_slot, const int32_t* up_nbr,
+                  int32_t n_upper, int32_t max_level, vsr_hnsw** out);
+int vsr_hnsw_free(vsr_hnsw* index);   /* before vsr_corpus_free of its corpus */
+int vsr_hnsw_search(vsr_hnsw* index, const float* queries, int nq, int dim, int k, int ef_search, int metric,
+                    const vsr_filter* const* filters,
+                    int64_t* out_block_ids, int32_t* out_doc_ids, int64_t* out_rows, float* out_dist, int32_t* out_counts,
+                    int64_t* out_visited);
+
 /* opclass support functions for n vectors at once (host pointers): vector_norm (vector.c:756-769), l2_normalize
  * (vector.c:774-808; fails with "value out of range: overflow" like float_overflow_error) and
  * vector_spherical_distance (vector.c:692-711; unit vectors assumed, as IVFFlat's spherical k-means uses it) */

@@ -7,6 +7,7 @@ distances are compared bit for bit."""
 import numpy as np
 import pytest
 
+from oracle.oracle import HnswIndex as OracleHnsw
 from oracle.oracle import IvfIndex as OracleIvf
 
 pytestmark = pytest.mark.gpu
@@ -95,5 +96,71 @@ def test_ivf_cosine_opclass_on_unit_rows(ctx, oracle):
         assert len(set(res.rows[i].tolist()) & set(idx.tolist())) >= 49
         np.testing.assert_allclose(res.dist[i], dist, rtol=1e-4, atol=1e-4)
     assert agree >= 19
+    gpu.free()
+    corpus.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# K4: HNSW layer search.  Same graph (exported from the oracle's pgvector-faithful build) => the GPU search returns the
+# rows the oracle's GetScanItems returns, in the same order, and visits the same number of elements, for
+# ef_search in {10, 40, 500}; recall@k against the exact scan is reported by the same test.
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def hnsw20k(oracle):
+    rng = np.random.default_rng(81)
+    n, dim = 20_000, 128
+    x = np.clip(np.rint(np.abs(rng.normal(0, 45, (n, dim)))), 0, 255).astype(np.float32)
+    x[5000:5040] = x[100]                              # 41 copies of one vector: elements with 10 heap TIDs each
+    blk = (np.arange(n) + 1).astype(np.int64)
+    doc = (np.arange(n) // 20 + 1).astype(np.int32)
+    h = OracleHnsw(oracle, "l2", x, m=16, ef_construction=64, seed=4)
+    return x, blk, doc, h
+
+
+@pytest.mark.parametrize("ef", [10, 40, 500])
+def test_hnsw_search_matches_the_oracle(ctx, oracle, hnsw20k, ef):
+    import vsrbac
+    x, blk, doc, oh = hnsw20k
+    n = len(x)
+    rng = np.random.default_rng(82 + ef)
+    corpus = ctx.load_corpus(x, blk, doc)
+    ndocs = int(doc.max())
+    perms = [(1, int(d)) for d in rng.choice(np.arange(1, ndocs + 1), ndocs // 4, replace=False)]
+    ur = [(1, 1)]
+    corpus.load_rbac(ur, perms)
+    gpu = corpus.load_hnsw(oh.export())
+    nq, k = 24, min(ef, 100)
+    qrows = rng.integers(0, n, nq)
+    qrows[0] = 100                                     # the duplicated vector
+    q = x[qrows] + rng.integers(-2, 3, (nq, x.shape[1])).astype(np.float32)
+    q[0] = x[100]
+    res, vis = gpu.search(q, k, ef, "l2")
+    hits = total = 0
+    for i in range(nq):
+        rows_o, dist_o, _, nv = oh.search(q[i], ef)
+        m = min(k, rows_o.size)
+        assert res.counts[i] == m, (i, res.counts[i], m)
+        np.testing.assert_array_equal(res.rows[i, :m], rows_o[:m])
+        np.testing.assert_array_equal(res.dist[i, :m], np.sqrt(dist_o[:m]).astype(np.float32))
+        assert vis[i] == nv, (i, vis[i], nv)
+        exact, _ = oracle.filtered_topk("l2", x, q[i], k, doc, blk)
+        hits += len(set(res.rows[i, :m].tolist()) & set(exact.tolist()))
+        total += k
+    print(f"hnsw ef_search={ef}: recall@{k} vs the exact scan = {hits / total:.3f}")
+    if ef >= 40:
+        assert hits / total >= 0.5                     # i.i.d. synthetic rows have no cluster structure; real SIFT is far higher
+    assert (res.dist[0, :10] == 0).all() and res.counts[0] >= 10        # one element's 10 TIDs come out together
+    # RLS semantics: the permission test is applied to the index's candidates, so fewer than k rows may come back
+    f = corpus.filter_for_user(1, vsrbac.BITMAP)
+    fr = corpus.filter_for_user(1, vsrbac.RANGES)
+    mask = oracle.user_row_mask(1, ur, perms, doc)
+    for flt in (f, fr):
+        resf, _ = gpu.search(q, k, ef, "l2", [flt] * nq)
+        for i in range(nq):
+            rows_o, dist_o, _, _ = oh.search(q[i], ef)
+            keep = rows_o[mask[rows_o] != 0][:k]
+            assert resf.counts[i] == keep.size
+            np.testing.assert_array_equal(resf.rows[i, :keep.size], keep)
+            assert (resf.block_ids[i, keep.size:] == -1).all()
     gpu.free()
     corpus.free()

@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256) void view_bitmap_kernel(const uint32_t* rank, 
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     bool ok = p < n_rows;
     if (ok) {
-        const uint32_t r = rank[p];
+        const uint32_t r = rank ? rank[p] : p;            // no rank map: the base corpus itself
         if (tiles) {
             uint32_t lo = 0, hi = n_tiles;                   // last tile with start <= r
             while (hi - lo > 1) {

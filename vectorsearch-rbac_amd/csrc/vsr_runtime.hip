@@ -2,6 +2,7 @@
 // No CPU compute path: every search / distance entry point launches HIP kernels or fails.
 #include "../../include/vsrbac.h"
 #include "vsr_device.h"
+#include "vsr_hnsw.h"
 
 #include <algorithm>
 #include <atomic>
@@ -2409,5 +2410,201 @@ extern "C" int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim
                             metric == VSR_METRIC_L2 ? M_L2 : M_IP, ivf->d_probe.as<int32_t>(), ctx->stream));
     HIPCHK(hipMemcpyAsync(out_lists, ivf->d_probe.p, (size_t) nq * probes * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return VSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: HNSW graph search (hnswscan.c:15-45, hnswutils.c:813-976) over a graph built elsewhere
+// ---------------------------------------------------------------------------------------------
+struct vsr_hnsw {
+    vsr_corpus* corpus = nullptr;
+    int32_t n_elem = 0, entry = -1, entry_level = -1, m = 0, max_level = 1;
+    int32_t *d_elem_row = nullptr, *d_level = nullptr, *d_nbr0 = nullptr, *d_up_slot = nullptr, *d_up_nbr = nullptr,
+            *d_tid_count = nullptr, *d_tids = nullptr;
+    std::map<const vsr_filter*, uint64_t*> bitmaps;  // filters without a full bitmap of their own, as one
+    DevBuf d_q, d_vis, d_out, d_bm;
+    PinBuf h_out;
+};
+
+extern "C" int vsr_hnsw_free(vsr_hnsw* h)
+{
+    if (!h) return VSR_OK;
+    if (h->corpus) {
+        (void) hipSetDevice(h->corpus->ctx->device);
+        (void) hipStreamSynchronize(h->corpus->ctx->stream);
+    }
+    void* ptrs[] = {h->d_elem_row, h->d_level, h->d_nbr0, h->d_up_slot, h->d_up_nbr, h->d_tid_count, h->d_tids};
+    for (void* p : ptrs)
+        if (p) (void) hipFree(p);
+    for (auto& kv : h->bitmaps)
+        if (kv.second) (void) hipFree(kv.second);
+    h->d_q.release(); h->d_vis.release(); h->d_out.release(); h->d_bm.release(); h->h_out.release();
+    delete h;
+    return VSR_OK;
+}
+
+extern "C" int vsr_hnsw_load(vsr_corpus* c, int m, int32_t n_elem, int32_t entry, const int32_t* level, const int32_t* nbr0,
+                             const int32_t* tid_count, const int64_t* tids, const int32_t* up_slot, const int32_t* up_nbr,
+                             int32_t n_upper, int32_t max_level, vsr_hnsw** out)
+{
+    if (!c || !out) return fail(VSR_ERR_INVALID, "vsr_hnsw_load: NULL argument");
+    *out = nullptr;
+    if (c->base) return fail(VSR_ERR_INVALID, "vsr_hnsw_load: the corpus is a view");
+    if (m < 2 || m > 32) return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_load: m must be between 2 and 32 (got %d)", m);   // 2m ids per wave
+    if (n_elem < 0 || (n_elem > 0 && (!level || !nbr0 || !tid_count || !tids || !up_slot)) || max_level < 1 || n_upper < 0 ||
+        (n_upper > 0 && !up_nbr) || entry >= n_elem)
+        return fail(VSR_ERR_INVALID, "vsr_hnsw_load: bad graph arrays");
+    vsr_ctx* ctx = c->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::unique_ptr<vsr_hnsw> h(new vsr_hnsw());
+    h->corpus = c;
+    h->n_elem = n_elem;
+    h->entry = n_elem > 0 ? entry : -1;
+    h->m = m;
+    h->max_level = max_level;
+    // heap TIDs arrive as caller row indices; the kernels work on internal rows
+    std::vector<int32_t> inv((size_t) std::max<int64_t>(c->n, 1), -1);
+    for (int64_t r = 0; r < c->n; ++r) inv[(size_t) c->h_orig[(size_t) r]] = (int32_t) r;
+    std::vector<int32_t> itids((size_t) std::max(n_elem, 1) * 10, -1), erow((size_t) std::max(n_elem, 1), 0);
+    for (int32_t e = 0; e < n_elem; ++e) {
+        if (tid_count[e] < 1 || tid_count[e] > 10 || level[e] < 0 || level[e] > max_level)
+            return fail(VSR_ERR_INVALID, "vsr_hnsw_load: element %d has %d heap TIDs / level %d", e, tid_count[e], level[e]);
+        for (int t = 0; t < tid_count[e]; ++t) {
+            const int64_t row = tids[(size_t) e * 10 + t];
+            if (row < 0 || row >= c->n) return fail(VSR_ERR_INVALID, "vsr_hnsw_load: element %d points at row %lld", e, (long long) row);
+            itids[(size_t) e * 10 + t] = inv[(size_t) row];
+        }
+        erow[(size_t) e] = itids[(size_t) e * 10];
+        for (int j = 0; j < 2 * m; ++j)
+            if (nbr0[(size_t) e * 2 * m + j] >= n_elem) return fail(VSR_ERR_INVALID, "vsr_hnsw_load: neighbour out of range");
+    }
+    h->entry_level = h->entry >= 0 ? level[h->entry] : -1;
+    auto up = [&](int32_t** d, const int32_t* src, size_t count) -> int {
+        HIPCHK(hipMalloc(d, std::max<size_t>(4, count * sizeof(int32_t))));
+        if (count) HIPCHK(hipMemcpy(*d, src, count * sizeof(int32_t), hipMemcpyHostToDevice));
+        return VSR_OK;
+    };
+    int rc;
+    if ((rc = up(&h->d_elem_row, erow.data(), (size_t) n_elem)) || (rc = up(&h->d_level, level, (size_t) n_elem)) ||
+        (rc = up(&h->d_nbr0, nbr0, (size_t) n_elem * 2 * m)) || (rc = up(&h->d_up_slot, up_slot, (size_t) n_elem)) ||
+        (rc = up(&h->d_up_nbr, up_nbr, (size_t) n_upper * max_level * m)) || (rc = up(&h->d_tid_count, tid_count, (size_t) n_elem)) ||
+        (rc = up(&h->d_tids, itids.data(), (size_t) n_elem * 10))) {
+        vsr_hnsw_free(h.release());
+        return rc;
+    }
+    *out = h.release();
+    return VSR_OK;
+}
+
+// the rows a filter admits as a bitmap over internal rows
+static int hnsw_filter_bitmap(vsr_hnsw* h, const vsr_filter* f, const uint64_t** out)
+{
+    vsr_corpus* c = h->corpus;
+    if (f->mode == VSR_FILTER_BITMAP && f->d_bitmap) {       // role / byte-mask filters in post-filter mode: already one
+        *out = f->d_bitmap;
+        return VSR_OK;
+    }
+    auto it = h->bitmaps.find(f);
+    if (it == h->bitmaps.end()) {
+        uint64_t* d = nullptr;
+        const size_t words = bitmap_words(c->n);
+        HIPCHK(hipMalloc(&d, words * sizeof(uint64_t)));
+        HIPCHK(hipMemsetAsync(d, 0, words * sizeof(uint64_t), c->ctx->stream));
+        HIPCHK(launch_view_bitmap(nullptr, (uint32_t) c->n, f->d_tiles, f->n_tiles, f->d_bitmap, d, c->ctx->stream));
+        it = h->bitmaps.emplace(f, d).first;
+    }
+    *out = it->second;
+    return VSR_OK;
+}
+
+extern "C" int vsr_hnsw_search(vsr_hnsw* h, const float* queries, int nq, int dim, int k, int ef, int metric,
+                               const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
+                               float* out_dist, int32_t* out_cnt, int64_t* out_visited)
+{
+    if (!h) return fail(VSR_ERR_INVALID, "vsr_hnsw_search: index is NULL");
+    vsr_corpus* c = h->corpus;
+    int rc = check_search_args(c, queries, nq, dim, k, metric, filters, "vsr_hnsw_search");
+    if (rc) return rc;
+    if (metric == VSR_METRIC_L1) return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_search: L1 graphs are not supported");
+    if (ef < 1 || ef > 1000) return fail(VSR_ERR_INVALID, "vsr_hnsw_search: ef_search must be between 1 and 1000 (got %d)", ef);   /* hnsw.c:86-89 */
+    if (nq == 0) return VSR_OK;
+    if (!out_blk || !out_dist || !out_cnt) return fail(VSR_ERR_INVALID, "vsr_hnsw_search: output is NULL");
+    vsr_ctx* ctx = c->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t qfloats = (size_t) c->stride4 * 4;
+    const uint32_t vwords = (uint32_t) ((std::max(h->n_elem, 1) + 31) / 32);
+    const int chunk = (int) std::max<size_t>(1, std::min<size_t>((size_t) nq, ((size_t) 256 << 20) / ((size_t) vwords * 4)));
+    const size_t nk = (size_t) chunk * k;
+    const size_t o_blk = 0, o_row = align_up(o_blk + nk * 8, 256), o_doc = align_up(o_row + nk * 8, 256),
+                 o_dist = align_up(o_doc + nk * 4, 256), o_cnt = align_up(o_dist + nk * 4, 256),
+                 o_vis = align_up(o_cnt + (size_t) chunk * 4, 256), total = align_up(o_vis + (size_t) chunk * 8, 256);
+    if ((rc = h->d_q.reserve((size_t) chunk * qfloats * sizeof(float)))) return rc;
+    if ((rc = h->d_vis.reserve((size_t) chunk * vwords * 4))) return rc;
+    if ((rc = h->d_out.reserve(total))) return rc;
+    if ((rc = h->h_out.reserve(total))) return rc;
+    if ((rc = h->d_bm.reserve((size_t) chunk * sizeof(uint64_t*)))) return rc;
+    std::vector<float> qpad((size_t) chunk * qfloats);
+    std::vector<const uint64_t*> bms((size_t) chunk);
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int n = std::min(chunk, nq - q0);
+        std::fill(qpad.begin(), qpad.end(), 0.0f);
+        bool any_filter = false;
+        for (int i = 0; i < n; ++i) {
+            memcpy(&qpad[(size_t) i * qfloats], queries + (size_t) (q0 + i) * dim, (size_t) dim * sizeof(float));
+            bms[(size_t) i] = nullptr;
+            if (filters && filters[q0 + i]) {
+                if ((rc = hnsw_filter_bitmap(h, filters[q0 + i], &bms[(size_t) i]))) return rc;
+                any_filter = true;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(h->d_q.p, qpad.data(), (size_t) n * qfloats * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h->d_bm.p, bms.data(), (size_t) n * sizeof(uint64_t*), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(h->d_vis.p, 0, (size_t) n * vwords * 4, ctx->stream));
+        char* d = h->d_out.as<char>();
+        HnswParams p{};
+        p.rows = c->d_rows;
+        p.stride4 = c->stride4;
+        p.metric = metric;
+        p.queries = h->d_q.as<float>();
+        p.n_elem = (uint32_t) h->n_elem;
+        p.entry = h->entry;
+        p.entry_level = h->entry_level;
+        p.m = (uint32_t) h->m;
+        p.max_level = (uint32_t) h->max_level;
+        p.elem_row = h->d_elem_row;
+        p.nbr0 = h->d_nbr0;
+        p.up_slot = h->d_up_slot;
+        p.up_nbr = h->d_up_nbr;
+        p.level = h->d_level;
+        p.tid_count = h->d_tid_count;
+        p.tids = h->d_tids;
+        p.bitmaps = any_filter ? h->d_bm.as<const uint64_t*>() : nullptr;
+        p.ef = (uint32_t) ef;
+        p.k = (uint32_t) k;
+        p.caps = (uint32_t) (2 * ef + 2 * h->m + 64);
+        p.visited = h->d_vis.as<uint32_t>();
+        p.visited_words = vwords;
+        p.block_ids = c->d_block;
+        p.doc_ids = c->d_doc;
+        p.orig_rows = c->d_orig;
+        p.out_block = reinterpret_cast<int64_t*>(d + o_blk);
+        p.out_doc = reinterpret_cast<int32_t*>(d + o_doc);
+        p.out_row = reinterpret_cast<int64_t*>(d + o_row);
+        p.out_dist = reinterpret_cast<float*>(d + o_dist);
+        p.out_count = reinterpret_cast<int32_t*>(d + o_cnt);
+        p.out_visited = reinterpret_cast<int64_t*>(d + o_vis);
+        p.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;
+        HIPCHK(launch_hnsw_search(p, (uint32_t) n, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h->h_out.p, d, total, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const char* hh = h->h_out.as<char>();
+        const size_t off = (size_t) q0 * k, cnt = (size_t) n * k;
+        memcpy(out_blk + off, hh + o_blk, cnt * 8);
+        if (out_row) memcpy(out_row + off, hh + o_row, cnt * 8);
+        if (out_doc) memcpy(out_doc + off, hh + o_doc, cnt * 4);
+        memcpy(out_dist + off, hh + o_dist, cnt * 4);
+        memcpy(out_cnt + q0, hh + o_cnt, (size_t) n * 4);
+        if (out_visited) memcpy(out_visited + q0, hh + o_vis, (size_t) n * 8);
+    }
     return VSR_OK;
 }

@@ -251,6 +251,11 @@ class Corpus:
         """IVFFlat index over this corpus: centres [lists, dim] and the list of every row (caller row order)."""
         return IvfIndex(self, centers, row_list)
 
+    def load_hnsw(self, graph):
+        """HNSW graph over this corpus; `graph`: dict with m, entry, level, nbr0, tid_count, tids, up_slot, up_nbr,
+        max_level (the layout oracle.HnswIndex.export() and a pgvector build dump produce)."""
+        return HnswIndex(self, graph)
+
     # ---- search ------------------------------------------------------------------------------
     def pack_filters(self, filters):
         """One filter per query as a reusable C array (build it once when the same batch shape repeats)."""
@@ -345,3 +350,47 @@ class IvfIndex:
                                        _ptr(doc), _ptr(row), _ptr(dist), _ptr(cnt)))
         del keep
         return SearchResult(blk, doc, row, dist, cnt)
+
+
+class HnswIndex:
+    """pgvector's hnsw scan (hnswscan.c) on the GPU: greedy descent, ef_search beam on layer 0, TIDs, filter, LIMIT."""
+
+    def __init__(self, corpus, g):
+        self.corpus, self._lib = corpus, corpus._lib
+        a = lambda name, dt: np.ascontiguousarray(g[name], dtype=dt)
+        level, nbr0, tc, tids = a("level", np.int32), a("nbr0", np.int32), a("tid_count", np.int32), a("tids", np.int64)
+        up_slot, up_nbr = a("up_slot", np.int32), a("up_nbr", np.int32)
+        n_upper = int((up_slot >= 0).sum())
+        h = C.c_void_p()
+        check(self._lib.vsr_hnsw_load(corpus._h, int(g["m"]), level.size, int(g["entry"]), _ptr(level), _ptr(nbr0), _ptr(tc),
+                                      _ptr(tids), _ptr(up_slot), _ptr(up_nbr), n_upper, int(g["max_level"]), C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.vsr_hnsw_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self.corpus._h:
+                self.free()
+        except Exception:
+            pass
+
+    def search(self, queries, k, ef_search=40, metric="l2", filters=None):
+        """SearchResult plus, as a second value, the number of elements each query visited on layer 0."""
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries, dtype=np.float32)))
+        nq, dim = q.shape
+        farr, keep = self.corpus._filter_array(filters, nq)
+        kk = max(int(k), 1)
+        blk = np.full((nq, kk), -1, dtype=np.int64)
+        doc = np.full((nq, kk), -1, dtype=np.int32)
+        row = np.full((nq, kk), -1, dtype=np.int64)
+        dist = np.full((nq, kk), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.int32)
+        vis = np.zeros(nq, dtype=np.int64)
+        check(self._lib.vsr_hnsw_search(self._h, _ptr(q), nq, dim, int(k), int(ef_search), _metric(metric), farr, _ptr(blk),
+                                        _ptr(doc), _ptr(row), _ptr(dist), _ptr(cnt), _ptr(vis)))
+        del keep
+        return SearchResult(blk, doc, row, dist, cnt), vis
