@@ -5,8 +5,9 @@
 // heap TIDs of the result elements nearest first (newest TID of an element first, hnswscan.c:278-311), the permission bit
 // of every row (the executor's RLS filter above the index scan) and the first k.
 //
-// Candidates are totally ordered by key = (monotone fp32 index distance << 32) | element id, the order the index oracle
-// (oracle/vsr_index_oracle.c) uses where pgvector's pairing heaps leave equal distances to insertion history.  Both of
+// Candidates are totally ordered by key = (monotone fp32 index distance << 32) | element id: a fixed choice where
+// pgvector's pairing heaps leave candidates of equal distance to insertion history (the tests' CPU checker makes the
+// same choice).  Both of
 // Algorithm 2's sets live in ONE sorted array S in LDS: every element ever pushed, with an "expanded" flag.  W (the ef
 // best found) is S's first min(pushed, ef) entries, C (still to expand) its unexpanded entries.  An expansion reads the
 // neighbour list (2m ids on layer 0), marks them in the query's visited bitmap (global memory, one atomicOr each), computes

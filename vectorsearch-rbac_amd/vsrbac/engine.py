@@ -253,7 +253,7 @@ class Corpus:
 
     def load_hnsw(self, graph):
         """HNSW graph over this corpus; `graph`: dict with m, entry, level, nbr0, tid_count, tids, up_slot, up_nbr,
-        max_level (the layout oracle.HnswIndex.export() and a pgvector build dump produce)."""
+        max_level (include/vsrbac.h, vsr_hnsw_load: what a dump of pgvector's in-memory build holds)."""
         return HnswIndex(self, graph)
 
     # ---- search ------------------------------------------------------------------------------
