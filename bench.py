@@ -474,6 +474,31 @@ def main():
         }
         out["cpu_baseline"]["all_cores"] = {"value": round(m / cpu_all_s, 1), "unit": "queries/s", "threads": threads,
                                             "note": "same sample, queries fanned over host threads"}
+        # CPU baseline no. 2: pgvector's HNSW (restated in oracle/vsr_index_oracle.c) with the index parameters of the
+        # reference's role-partition experiment (m = 16, ef_construction = 64; test_partition_prefilter_by_role.py:42-46),
+        # one core, on a bounded sample: the first 30k rows of one role partition, 100 queries per ef_search
+        try:
+            from oracle.oracle import HnswIndex
+            rows_idx = np.concatenate([np.arange(s0, s0 + c0) for s0, c0 in ranges[0]])[:30000]
+            sub = np.ascontiguousarray(x[rows_idx])
+            tb = time.perf_counter()
+            hidx = HnswIndex(orc, "l2", sub, m=16, ef_construction=64, seed=args.seed)
+            build_s = time.perf_counter() - tb
+            hq = qvec[:100]
+            exact = [set(orc.filtered_topk("l2", sub, hq[i], k)[0].tolist()) for i in range(len(hq))]
+            sweep = []
+            for ef in (40, 200, 500):
+                th = time.perf_counter()
+                got = [hidx.search(hq[i], ef)[0][:k] for i in range(len(hq))]
+                hs = time.perf_counter() - th
+                rec = float(np.mean([len(set(g.tolist()) & e) / max(1, len(e)) for g, e in zip(got, exact)]))
+                sweep.append({"ef_search": ef, "qps": round(len(hq) / hs, 1), "recall_at_k": round(rec, 4)})
+            out["cpu_baseline"]["hnsw"] = {
+                "kind": "port", "cores": 1, "m": 16, "ef_construction": 64, "rows": int(len(sub)), "build_s": round(build_s, 2),
+                "sweep": sweep, "sample": "pgvector's HNSW restated (oracle/vsr_index_oracle.c), first 30k rows of one role "
+                                          "partition, 100 queries per ef_search, recall against the exact scan of those rows"}
+        except Exception as exc:      # the baseline is reported, never required
+            out["cpu_baseline"]["hnsw"] = {"error": repr(exc)}
         checks = {leg: spot_check(leg, orc, m) for leg in legs}
         out["parity_spot_check"] = checks[legs[0]]
         for leg in legs[1:]:
