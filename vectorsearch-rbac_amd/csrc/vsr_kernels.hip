@@ -939,20 +939,10 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(const RerankParams p
     const uint32_t cnt = p.qcnt[slot];
     const uint32_t n = cnt < p.capq ? cnt : p.capq;
     if (tid < 64) {
-        constexpr int R = GQ_CAP / 64;
-        const uint64_t* cq = p.qcand + (size_t) slot * p.capq;
-        uint64_t reg[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = (uint32_t) (r * 64 + lane);
-            reg[r] = cq[i < n ? i : 0u];
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((uint32_t) (r * 64 + lane) >= n) reg[r] = KEY_EMPTY;
-        uint64_t tsel, kth;
-        wave_radix_select<R>(reg, n, p.kp, hist, lane, tsel, kth);
-        const uint32_t want = wave_emit_selected<R>(reg, n, p.kp, tsel, kth, keys, lane);
+        // 1024 candidates at a time (16 keys per lane): the registers of this kernel stay few enough for every query of a
+        // 1000-query batch to be resident at once, and typical buffers (a few hundred to ~1500 keys) take 1-2 rounds
+        uint64_t kth;
+        const uint32_t want = wave_select_stream<16>(p.qcand + (size_t) slot * p.capq, n, p.kp, keys, hist, lane, kth);
         for (uint32_t i = want + (uint32_t) lane; i < np2; i += 64) keys[i] = KEY_EMPTY;
         if (lane == 0) s_worst = n >= p.kp ? kth : KEY_EMPTY;
     }
@@ -978,25 +968,15 @@ __global__ __launch_bounds__(256) void seed_select_kernel(const uint64_t* samp, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t q = blockIdx.x * 4 + (uint32_t) wave;
     if (q >= n_queries) return;                              // wave-uniform; no workgroup barrier below
-    constexpr int R = GQ_SAMPLE_CAP / 64;
+    __shared__ uint64_t sm_keep[4][GQ_SAMPLE_CAP / 4];
     const uint32_t cnt = samp_cnt[q];
     const uint32_t n = cnt < cap ? cnt : cap;
-    const uint64_t* cq = samp + (size_t) q * cap;
-    uint64_t reg[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t i = (uint32_t) (r * 64 + lane);
-        reg[r] = cq[i < n ? i : 0u];
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if ((uint32_t) (r * 64 + lane) >= n) reg[r] = KEY_EMPTY;
     // a buffer that overflowed holds a subset of the sample: the effective sampling fraction shrinks with it
     const float lambda = kp_frac * (cnt > n ? (float) n / (float) cnt : 1.0f);
     const uint32_t m = (uint32_t) ceilf(lambda + 6.0f * sqrtf(lambda)) + 4u;
-    uint64_t tsel, kth;
-    wave_radix_select<R>(reg, n, m, sm_hist[wave], lane, tsel, kth);
-    if (lane == 0) tau[q] = n >= m ? (kth | 0xFFFFFFFFull) : KEY_EMPTY;
+    uint64_t kth = KEY_EMPTY;
+    if (n >= m && m < 1024) (void) wave_select_stream<16>(samp + (size_t) q * cap, n, m, sm_keep[wave], sm_hist[wave], lane, kth);
+    if (lane == 0) tau[q] = (n >= m && m < 1024) ? (kth | 0xFFFFFFFFull) : KEY_EMPTY;
 }
 
 hipError_t launch_seed_select(const uint64_t* samp, const uint32_t* samp_cnt, uint32_t cap, float kp_frac, uint64_t* tau,

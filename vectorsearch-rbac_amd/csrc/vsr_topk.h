@@ -215,6 +215,41 @@ __device__ __forceinline__ uint32_t wave_emit_selected(const uint64_t (&reg)[R],
     return want;
 }
 
+// The `keep` smallest of a long key stream src[0 .. n) by ONE wave holding only 64 * R keys at a time: a chunk of the stream
+// joins the survivors so far, the radix select keeps `keep` of them, and so on (the keep smallest of a union are among
+// the keep smallest of its parts).  Survivors live in `out` (LDS or global, >= keep keys), unordered except that the
+// largest goes last when n >= keep.  Returns min(keep, n); kth = the largest survivor.  Needs keep < 64 * R.
+template <int R>
+__device__ __forceinline__ uint32_t wave_select_stream(const uint64_t* src, uint32_t n, uint32_t keep, uint64_t* out,
+                                                       uint32_t* hist, int lane, uint64_t& kth)
+{
+    uint32_t have = 0, pos = 0;
+    kth = KEY_EMPTY;
+    do {
+        const uint32_t room = (uint32_t) (64 * R) - have;
+        const uint32_t take = n - pos < room ? n - pos : room;
+        uint64_t reg[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = (uint32_t) (r * 64 + lane);
+            uint64_t v = KEY_EMPTY;
+            if (i < have) v = out[i];
+            else if (i - have < take) v = src[pos + (i - have)];
+            reg[r] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n_real = have + take;
+        uint64_t tsel;
+        wave_radix_select<R>(reg, n_real, keep, hist, lane, tsel, kth);
+        have = wave_emit_selected<R>(reg, n_real, keep, tsel, kth, out, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        pos += take;
+    } while (pos < n);
+    return have;
+}
+
 // Keep the k smallest keys (sorted) and lower tau.  Must be called by all threads, after a barrier
 // that orders every append before it.  `always_sort` forces sorted output even when count <= k.
 template <int NT>
