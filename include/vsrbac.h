@@ -80,7 +80,9 @@ const char* vsr_status_string(int status);
 
 int vsr_open(int device_ordinal, vsr_ctx** out);
 int vsr_close(vsr_ctx* ctx);
-/* use the caller's HIP stream (hipStream_t as void*, e.g. torch's current stream); NULL = own stream */
+/* use the caller's HIP stream (hipStream_t as void*, e.g. torch's current stream); NULL = the context's own
+ * non-blocking stream.  HIP's null stream has the handle 0 as well: name it as VSR_STREAM_NULL (= hipStreamLegacy). */
+#define VSR_STREAM_NULL ((void*) 1)
 int vsr_set_stream(vsr_ctx* ctx, void* hip_stream);
 int vsr_synchronize(vsr_ctx* ctx);
 int vsr_device_info(vsr_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* hbm_bytes);

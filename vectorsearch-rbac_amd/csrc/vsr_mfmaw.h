@@ -25,9 +25,14 @@
 // mapping of a tile (tile descriptor -> row -> permission bit, |row|^2) is resolved by wave 0 up to 3 * DEPTH tiles
 // ahead, one dependent load per DEPTH tiles, so its latency is covered like that of the row data.
 //
-// Candidates: every query of the call owns ONE buffer of `capq` keys in global memory (ScanParams::qcand / qcnt).  A lane
-// whose screening values pass the query's threshold reserves room with one returning atomic and stores its keys; there
-// are no per-workgroup lists, no in-kernel compaction and no publish phase.  The thresholds come from a sample pass of
+// Candidates: every query of the call owns ONE buffer of `capq` keys in global memory (ScanParams::qcand / qcnt); there
+// are no per-workgroup lists, no in-kernel compaction and no publish phase.  Room in a buffer is reserved with a
+// RETURNING global atomic, and waiting for its result means s_waitcnt vmcnt(0): the row loads prefetched for the next
+// tiles would be drained with it at every tile that has a survivor -- nearly all of them (64 x 64 pairs per tile).  So
+// the main pass parks a wave's survivors {value, row, query slot} in a wave-private LDS ring (the position is the wave's
+// running count, no atomic at all) and flushes them in two phases that ride on the row pipeline: the atomics (one per
+// parked entry) are issued just before a tile's row loads, and the keys are stored after the next tile's rows have been
+// waited for -- by then the positions are there too.  The sample pass (every row survives) reserves directly.  The thresholds come from a sample pass of
 // this same kernel (SAMPLE: every ss-th tile, threshold open, the query's sample buffer) through seed_select_kernel;
 // select_rerank_kernel (vsr_kernels.hip) then picks the kp best of a query's buffer and re-ranks them exactly.  A buffer
 // that overflows (count > capq) only loses candidates and is flagged there: the caller re-runs that query exactly.
@@ -54,6 +59,11 @@ constexpr int MW_RING = 8;                 // row-mapping ring (tiles): >= DEPTH
 #endif
 #ifndef VSR_MW_OCC1
 #define VSR_MW_OCC1 3
+#endif
+// Development ablations (-DVSR_ABLATE=bits, variant libraries only; results are wrong by construction): 1 = survivors are
+// counted but never appended, 2 = no epilogue at all, 4 = no MFMA / A-fragment reads, 8 = row loads only for the first tile.
+#ifndef VSR_ABLATE
+#define VSR_ABLATE 0
 #endif
 constexpr int mw_depth(int nch) { return nch == 1 ? VSR_MW_DEPTH1 : nch == 2 ? 2 : 1; }
 constexpr int mw_occ(int nch) { return nch == 1 ? VSR_MW_OCC1 : 2; }
@@ -107,6 +117,10 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     unsigned char* after = smem + 2 * MW_ROWS * MW_S * 16;
     int32_t*  rowidx = reinterpret_cast<int32_t*>(after);                       // [MW_RING][64]
     float*    rownorm = reinterpret_cast<float*>(after + MW_RING * 64 * 4);     // [MW_RING][64]
+    unsigned char* pend = after + MW_RING * 64 * 8;                             // parked survivors, per wave
+    float*    pend_v = reinterpret_cast<float*>(pend) + (size_t) wave * MW_PEND;
+    uint32_t* pend_r = reinterpret_cast<uint32_t*>(pend + 4 * MW_PEND * 4) + (size_t) wave * MW_PEND;
+    uint32_t* pend_s = reinterpret_cast<uint32_t*>(pend + 8 * MW_PEND * 4) + (size_t) wave * MW_PEND;
 
     // ---- wave roles ----
     const uint32_t ngt = (q_count + MF_NQ - 1) / MF_NQ;                         // 16-query groups of this pass (1..4)
@@ -150,7 +164,8 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     const uint32_t n_it = (n_super + ss - 1) / ss;
     const bool qok = my_qi < q_count;
     const bool open = my_tau == KEY_EMPTY;
-    const float tau_f = mono_to_float((uint32_t) (my_tau >> 32));
+    // screening limit: a value passes unless it is greater (NaN values pass; an open threshold admits everything)
+    const float tau_lim = open ? __builtin_inff() : mono_to_float((uint32_t) (my_tau >> 32));
     uint64_t* my_cand = p.qcand + (size_t) my_slot * p.capq;
     uint32_t* my_cnt = p.qcnt + my_slot;
 
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
         for (int u = 0; u < 4; ++u) {
             const int32_t r = ridx[u * 16 + lrow];
             const uint32_t rc = (uint32_t) (r < 0 ? 0 : r);
+            if ((VSR_ABLATE & 8) && it_ > 0) continue;
             const u32x4 v = *reinterpret_cast<const u32x4*>(p.scr + (size_t) (rc < last_row ? rc : last_row) * pstride4 + chunk);
             X[D][S][u] = make_uint4(v[0], v[1], v[2], v[3]);
         }
@@ -250,6 +266,40 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     if constexpr (DEPTH > 1) issue_tile(std::integral_constant<int, 1>{}, 1);
     if constexpr (DEPTH > 2) issue_tile(std::integral_constant<int, 2>{}, 2);
     if constexpr (DEPTH > 3) issue_tile(std::integral_constant<int, 3>{}, 3);
+
+    // parked survivors -> their queries' buffers (all lanes of the wave; the wave's LDS operations complete in order)
+    // Parking ring of this wave (wave-uniform bookkeeping, scalar registers): entries [p_head, p_tail) are parked; the
+    // first f_n of them have their buffer positions on the way (f_at: one returning atomic per entry, issued in phase A
+    // right BEFORE a tile's row loads, so that the wait for those loads at the next tile covers the atomics as well and
+    // phase B -- the key stores -- never waits for anything of its own).
+    uint32_t p_head = 0, p_tail = 0, f_n = 0;
+    constexpr int FL_R = 2;                                        // flush rounds: up to 64 * FL_R entries at a time
+    uint32_t f_at[FL_R];
+#pragma unroll
+    for (int r = 0; r < FL_R; ++r) f_at[r] = 0;
+    auto flush_issue = [&]() {                                     // phase A
+        const uint32_t have = p_tail - p_head;
+        f_n = have < 64u * FL_R ? have : 64u * FL_R;
+#pragma unroll
+        for (int r = 0; r < FL_R; ++r) {
+            const uint32_t e = (uint32_t) (r * 64 + lane);
+            if (e < f_n) f_at[r] = atomicAdd(p.qcnt + pend_s[(p_head + e) % MW_PEND], 1u);
+        }
+    };
+    auto flush_store = [&]() {                                     // phase B
+#pragma unroll
+        for (int r = 0; r < FL_R; ++r) {
+            const uint32_t e = (uint32_t) (r * 64 + lane);
+            if (e < f_n) {
+                const uint32_t idx = (p_head + e) % MW_PEND;
+                const float v = pend_v[idx];
+                const uint32_t row = pend_r[idx], slot = pend_s[idx];
+                if (f_at[r] < p.capq) p.qcand[(size_t) slot * p.capq + f_at[r]] = make_key(v, g_rank ? g_rank[row] : row);
+            }
+        }
+        p_head += f_n;
+        f_n = 0;
+    };
 
     auto run = [&](auto nsc) {
         constexpr int NS = decltype(nsc)::value;                   // 16-row sub-tiles of this wave (1, 2 or 4)
@@ -270,14 +320,20 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
                     img[slot * MW_S + (lchunk ^ (slot & 15))] = X[D][S][u];      // XOR-swizzled image
                 }
                 if constexpr (S == 0) {                            // row mapping, one step per tile (see above)
+                    if constexpr (!SAMPLE) {
+                        if (f_n) flush_store();                    // the image write above waited for this tile's rows, which
+                    }                                              // were issued after the atomics: their results are here
                     finish_rows(it + DEPTH, pend_row[D], pend_bw[D], pend_nrm[D]);
                     start_rows(dsc_a[D], pend_row[D], pend_bw[D], pend_nrm[D]);
                     dsc_a[D] = fetch_desc(it + 3 * DEPTH);
                 }
                 lds_barrier();
+                if constexpr (S == 0 && !SAMPLE) {
+                    if (!f_n && p_tail - p_head >= 64u) flush_issue();
+                }
                 issue(dc, sc, it + DEPTH);                         // in flight under the work of DEPTH whole tiles (past the
                                                                    // last tile: all slots invalid, row 0 from the cache)
-                if (gact) {
+                if (gact && !(VSR_ABLATE & 4)) {
 #pragma unroll
                     for (int h0 = 0; h0 < NS; h0 += NH)
 #pragma unroll
@@ -310,7 +366,12 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
             // lane screens its pairs, reserves room in its query's buffer for all of its survivors with ONE returning
             // atomic and stores them.  Screening test in float: a value is a candidate unless it is greater than the
             // threshold's distance (NaN values and an open / NaN threshold pass): a superset of `key <= tau`.
-            if (gact) {
+            if (VSR_ABLATE & 2) {
+                float sink = 0.f;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+                if (sink == 12345.678f) atomicOr(p.err, 2u);
+            } else if (gact) {
                 const int32_t* ridx = rowidx + (it % MW_RING) * 64;
                 const float* rnrm = rownorm + (it % MW_RING) * 64;
                 uint32_t pmask = 0;
@@ -324,21 +385,73 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = screen_value<METRIC>(acc[i][r], nx4[r], my_qn);
-                        if (qok && rows4[r] >= 0 && (open || !(v > tau_f))) pmask |= 1u << (i * 4 + r);
+                        const uint32_t ok = (uint32_t) !(v > tau_lim) & (uint32_t) (rows4[r] >= 0) & (uint32_t) qok;   // no branches
+                        pmask |= ok << (i * 4 + r);
                     }
                 }
+                if (VSR_ABLATE & 1) {
+                    if (pmask == 0xFFFFFFFFu) atomicOr(p.err, 2u);
+                    pmask = 0;
+                }
                 if (__ballot(pmask != 0) != 0) {                   // wave-uniform
-                    if (pmask) {
-                        const uint32_t n = (uint32_t) __popc(pmask);
-                        const uint32_t base = atomicAdd(my_cnt, n);            // the count keeps growing past capq: overflow shows
+                    if constexpr (SAMPLE) {
+                        if (pmask) {
+                            const uint32_t n = (uint32_t) __popc(pmask);
+                            const uint32_t base = atomicAdd(my_cnt, n);        // the count keeps growing past capq: overflow shows
 #pragma unroll
-                        for (int j = 0; j < NS * 4; ++j)
-                            if (pmask & (1u << j)) {               // value and key are (re)built for survivors only
+                            for (int j = 0; j < NS * 4; ++j)
+                                if (pmask & (1u << j)) {           // value and key are (re)built for survivors only
+                                    const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
+                                    const uint32_t at = base + (uint32_t) __popc(pmask & ((1u << j) - 1u));
+                                    const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
+                                    if (at < p.capq) my_cand[at] = make_key(v, g_rank ? g_rank[ridx[slot]] : (uint32_t) ridx[slot]);
+                                }
+                        }
+                    } else {
+                        // one round per survivor of the busiest lane (1 - 2 at the usual ~1 % admission) instead of a
+                        // predicated body per result register: the parking position is the wave's running count (wave
+                        // uniform, in a scalar register) plus the lane's rank among the lanes of this round
+                        uint64_t act = __ballot(pmask != 0);
+                        while (act) {
+                            const uint32_t room = MW_PEND - (p_tail - p_head);
+                            if (pmask) {
+                                const int j = __builtin_ctz(pmask);
+                                pmask &= pmask - 1u;
                                 const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
-                                const uint32_t at = base + (uint32_t) __popc(pmask & ((1u << j) - 1u));
-                                const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
-                                if (at < p.capq) my_cand[at] = make_key(v, g_rank ? g_rank[ridx[slot]] : (uint32_t) ridx[slot]);
+                                float a;                           // acc[j >> 2][j & 3] by a select tree on the bits of j
+                                if constexpr (NS == 1) {
+                                    const float b0 = j & 1 ? acc[0][1] : acc[0][0], b1 = j & 1 ? acc[0][3] : acc[0][2];
+                                    a = j & 2 ? b1 : b0;
+                                } else {
+                                    float c[NS];
+#pragma unroll
+                                    for (int i = 0; i < NS; ++i) {
+                                        const float b0 = j & 1 ? acc[i][1] : acc[i][0], b1 = j & 1 ? acc[i][3] : acc[i][2];
+                                        c[i] = j & 2 ? b1 : b0;
+                                    }
+                                    if constexpr (NS == 2) a = j & 4 ? c[1] : c[0];
+                                    else {
+                                        const float d0 = j & 4 ? c[1] : c[0], d1 = j & 4 ? c[3] : c[2];
+                                        a = j & 8 ? d1 : d0;
+                                    }
+                                }
+                                const float v = screen_value<METRIC>(a, rnrm[slot], my_qn);
+                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (act >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t) act, 0u));
+                                if (rank < room) {
+                                    const uint32_t at = (p_tail + rank) % MW_PEND;
+                                    pend_v[at] = v;
+                                    pend_r[at] = (uint32_t) ridx[slot];
+                                    pend_s[at] = my_slot;
+                                } else {                           // the wave's parking ring is full (a burst): reserve directly
+                                    const uint32_t ga = atomicAdd(my_cnt, 1u);
+                                    if (ga < p.capq) my_cand[ga] = make_key(v, g_rank ? g_rank[ridx[slot]] : (uint32_t) ridx[slot]);
+                                }
                             }
+                            const uint32_t n_act = (uint32_t) __popcll(act);
+                            p_tail += n_act < room ? n_act : room;
+                            act = __ballot(pmask != 0);
+                        }
                     }
                 }
             }
@@ -355,6 +468,13 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     if (rsplit == 4) run(std::integral_constant<int, 1>{});
     else if (rsplit == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 4>{});
+    if constexpr (!SAMPLE) {                                                   // drain the parking ring
+        if (f_n) flush_store();
+        while (p_tail != p_head) {
+            flush_issue();
+            flush_store();
+        }
+    }
 
     if (bad_row) atomicOr(p.err, 1u);                                          // a tile reached past the corpus: results invalid
 }

@@ -50,7 +50,14 @@ class Context:
         return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
 
     def set_stream(self, stream_handle):
-        check(self._lib.vsr_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+        """A hipStream_t handle (torch: `stream.cuda_stream`).  None: the context's own stream.  0 is what torch reports
+        for the device's null stream: it is passed as VSR_STREAM_NULL, so that work the caller orders on that stream
+        (events, copies, collectives) really is ordered against the searches."""
+        if stream_handle is None:
+            handle = 0
+        else:
+            handle = int(stream_handle) or 1
+        check(self._lib.vsr_set_stream(self._h, C.c_void_p(handle)))
 
     def synchronize(self):
         check(self._lib.vsr_synchronize(self._h))
