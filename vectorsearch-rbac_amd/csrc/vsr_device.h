@@ -215,9 +215,8 @@ inline size_t mfmaw_lds_bytes()
     // two 64-row x 16-chunk stage buffers + the row-mapping ring + per wave {value, row, slot}[MW_PEND]
     return (size_t) 2 * 64 * 16 * 16 + 8 * 64 * 8 + (size_t) 4 * MW_PEND * 12;
 }
-constexpr uint32_t GQ_CAP = 4096;                       // candidate keys per query (one wave holds them all: 64 per lane)
-constexpr uint32_t GQ_SAMPLE_CAP = 4096;                // sampled keys per query kept for the threshold seed
-constexpr uint32_t GQ_MAX_ROWS = 128 * GQ_SAMPLE_CAP;   // a query's filter may admit this many rows (its 1/128 sample must fit)
+constexpr uint32_t GQ_CAP = 16384;                      // candidate keys per query (a filter this small needs no threshold at all)
+constexpr uint32_t GQ_SAMPLE_CAP = 4096;                // sampled minima per query kept for the threshold seed (more: dropped)
 constexpr uint32_t GQ_MAX_KP = 512;                     // screening survivors the fused select + re-rank handles
 inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 48; }   // d = 61 .. 192; longer rows: K2
 inline int  mfmaw_qmax(uint32_t stride4) { (void) stride4; return 64; }

@@ -32,7 +32,8 @@
 // the main pass parks a wave's survivors {value, row, query slot} in a wave-private LDS ring (the position is the wave's
 // running count, no atomic at all) and flushes them in two phases that ride on the row pipeline: the atomics (one per
 // parked entry) are issued just before a tile's row loads, and the keys are stored after the next tile's rows have been
-// waited for -- by then the positions are there too.  The sample pass (every row survives) reserves directly.  The thresholds come from a sample pass of
+// waited for -- by then the positions are there too.  The sample pass keeps only minima (see its epilogue) and reserves
+// directly.  The thresholds come from a sample pass of
 // this same kernel (SAMPLE: every ss-th tile, threshold open, the query's sample buffer) through seed_select_kernel;
 // select_rerank_kernel (vsr_kernels.hip) then picks the kp best of a query's buffer and re-ranks them exactly.  A buffer
 // that overflows (count > capq) only loses candidates and is flagged there: the caller re-runs that query exactly.
@@ -61,7 +62,7 @@ constexpr int MW_RING = 8;                 // row-mapping ring (tiles): >= DEPTH
 #define VSR_MW_OCC1 3
 #endif
 // Development ablations (-DVSR_ABLATE=bits, variant libraries only; results are wrong by construction): 1 = survivors are
-// counted but never appended, 2 = no epilogue at all, 4 = no MFMA / A-fragment reads, 8 = row loads only for the first tile.
+// counted but never appended, 2 = no epilogue at all, 4 = no MFMA / A-fragment reads, 8 = row loads only for the first tile, 16 = no tiles at all (prologue only).
 #ifndef VSR_ABLATE
 #define VSR_ABLATE 0
 #endif
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
 
     const uint32_t pstride4 = p.pstride4;
     const uint32_t q_count = grp.q_count;
+    const bool sample_fine = SAMPLE && (grp.partial_begin & 1u);               // sample pass: one entry per lane, not per column
 
     // LDS: [stage buffers | row index ring | |row|^2 ring]
     uint4*    stage = reinterpret_cast<uint4*>(smem);                           // [2][64 * MW_S]
@@ -118,9 +120,9 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     int32_t*  rowidx = reinterpret_cast<int32_t*>(after);                       // [MW_RING][64]
     float*    rownorm = reinterpret_cast<float*>(after + MW_RING * 64 * 4);     // [MW_RING][64]
     unsigned char* pend = after + MW_RING * 64 * 8;                             // parked survivors, per wave
-    float*    pend_v = reinterpret_cast<float*>(pend) + (size_t) wave * MW_PEND;
-    uint32_t* pend_r = reinterpret_cast<uint32_t*>(pend + 4 * MW_PEND * 4) + (size_t) wave * MW_PEND;
-    uint32_t* pend_s = reinterpret_cast<uint32_t*>(pend + 8 * MW_PEND * 4) + (size_t) wave * MW_PEND;
+    uint32_t* pend_v = reinterpret_cast<uint32_t*>(pend) + (size_t) wave * MW_PEND;                       // key high word
+    uint32_t* pend_r = reinterpret_cast<uint32_t*>(pend + 4 * MW_PEND * 4) + (size_t) wave * MW_PEND;     // row
+    uint32_t* pend_c = reinterpret_cast<uint32_t*>(pend + 8 * MW_PEND * 4) + (size_t) wave * MW_PEND;     // query column 0..15
 
     // ---- wave roles ----
     const uint32_t ngt = (q_count + MF_NQ - 1) / MF_NQ;                         // 16-query groups of this pass (1..4)
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
     const uint32_t n_super = (t1 - t0 + tps - 1) / tps;
     const uint32_t ss = p.sample_stride;                                        // sample pass: every ss-th tile
-    const uint32_t n_it = (n_super + ss - 1) / ss;
+    const uint32_t n_it = (VSR_ABLATE & 16) ? 0u : (n_super + ss - 1) / ss;
     const bool qok = my_qi < q_count;
     const bool open = my_tau == KEY_EMPTY;
     // screening limit: a value passes unless it is greater (NaN values pass; an open threshold admits everything)
@@ -268,37 +270,80 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     if constexpr (DEPTH > 3) issue_tile(std::integral_constant<int, 3>{}, 3);
 
     // parked survivors -> their queries' buffers (all lanes of the wave; the wave's LDS operations complete in order)
-    // Parking ring of this wave (wave-uniform bookkeeping, scalar registers): entries [p_head, p_tail) are parked; the
-    // first f_n of them have their buffer positions on the way (f_at: one returning atomic per entry, issued in phase A
-    // right BEFORE a tile's row loads, so that the wait for those loads at the next tile covers the atomics as well and
-    // phase B -- the key stores -- never waits for anything of its own).
+    // Parking ring of this wave (wave-uniform bookkeeping, scalar registers): entries [p_head, p_tail) are parked, each
+    // {key high word, row, query column of the wave's group}.  A flush takes the first f_n of them in two phases:
+    //   A (right BEFORE a tile's row loads are issued): the entries are counted per column with ballots and lane c < 16
+    //     reserves room for ALL entries of column c with ONE returning atomic on its query's counter -- atomics on one
+    //     address serialise at ~0.2 us each on this chip, so per-entry atomics (~600 per query) would cost more than the
+    //     whole scan;
+    //   B (after the next tile's rows have been waited for; the atomics were issued before those loads, so their results
+    //     are there too and nothing waits): entry -> position = its column's base + its rank, key stored.
     uint32_t p_head = 0, p_tail = 0, f_n = 0;
     constexpr int FL_R = 2;                                        // flush rounds: up to 64 * FL_R entries at a time
-    uint32_t f_at[FL_R];
+    uint32_t f_rank[FL_R];                                         // per lane and round: rank of its entry within the column
+    uint32_t f_base = 0;                                           // lanes 0..15: first position of column `lane`
 #pragma unroll
-    for (int r = 0; r < FL_R; ++r) f_at[r] = 0;
+    for (int r = 0; r < FL_R; ++r) f_rank[r] = 0;
     auto flush_issue = [&]() {                                     // phase A
         const uint32_t have = p_tail - p_head;
         f_n = have < 64u * FL_R ? have : 64u * FL_R;
+        uint32_t col[FL_R];
 #pragma unroll
         for (int r = 0; r < FL_R; ++r) {
             const uint32_t e = (uint32_t) (r * 64 + lane);
-            if (e < f_n) f_at[r] = atomicAdd(p.qcnt + pend_s[(p_head + e) % MW_PEND], 1u);
+            col[r] = e < f_n ? pend_c[(p_head + e) % MW_PEND] : 0xFFu;
         }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int c = 0; c < MF_NQ; ++c) {
+            uint32_t before = 0;
+#pragma unroll
+            for (int r = 0; r < FL_R; ++r) {
+                const uint64_t m = __ballot(col[r] == (uint32_t) c);
+                if (col[r] == (uint32_t) c)
+                    f_rank[r] = before + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+                before += (uint32_t) __popcll(m);
+            }
+            if (lane == c) mine = before;
+        }
+        if (lane < MF_NQ && mine) f_base = atomicAdd(my_cnt, mine);            // lane c < 16 is (kq 0, column c): its own query
     };
     auto flush_store = [&]() {                                     // phase B
 #pragma unroll
         for (int r = 0; r < FL_R; ++r) {
             const uint32_t e = (uint32_t) (r * 64 + lane);
+            const uint32_t idx = (p_head + e) % MW_PEND;
+            const uint32_t c = e < f_n ? pend_c[idx] : 0u;
+            const uint32_t base = (uint32_t) __shfl((int) f_base, (int) c);
+            const uint32_t slot = (uint32_t) __shfl((int) my_slot, (int) c);
             if (e < f_n) {
-                const uint32_t idx = (p_head + e) % MW_PEND;
-                const float v = pend_v[idx];
-                const uint32_t row = pend_r[idx], slot = pend_s[idx];
-                if (f_at[r] < p.capq) p.qcand[(size_t) slot * p.capq + f_at[r]] = make_key(v, g_rank ? g_rank[row] : row);
+                const uint32_t row = pend_r[idx];
+                const uint32_t at = base + f_rank[r];
+                if (at < p.capq)
+                    p.qcand[(size_t) slot * p.capq + at] = ((uint64_t) pend_v[idx] << 32) | (g_rank ? g_rank[row] : row);
             }
         }
         p_head += f_n;
         f_n = 0;
+    };
+    // one entry per lane with `has` (wave-uniform call): the position is the wave's running count + the lane's rank
+    auto park = [&](bool has, uint32_t key_hi, uint32_t row) {
+        const uint64_t act = __ballot(has);
+        const uint32_t room = MW_PEND - (p_tail - p_head);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) act, 0u));
+        if (has) {
+            if (rank < room) {
+                const uint32_t at = (p_tail + rank) % MW_PEND;
+                pend_v[at] = key_hi;
+                pend_r[at] = row;
+                pend_c[at] = (uint32_t) jq;
+            } else {                                               // the ring is full (a burst): reserve directly
+                const uint32_t ga = atomicAdd(my_cnt, 1u);
+                if (ga < p.capq) my_cand[ga] = ((uint64_t) key_hi << 32) | (g_rank ? g_rank[row] : row);
+            }
+        }
+        const uint32_t n_act = (uint32_t) __popcll(act);
+        p_tail += n_act < room ? n_act : room;
     };
 
     auto run = [&](auto nsc) {
@@ -320,16 +365,15 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
                     img[slot * MW_S + (lchunk ^ (slot & 15))] = X[D][S][u];      // XOR-swizzled image
                 }
                 if constexpr (S == 0) {                            // row mapping, one step per tile (see above)
-                    if constexpr (!SAMPLE) {
-                        if (f_n) flush_store();                    // the image write above waited for this tile's rows, which
-                    }                                              // were issued after the atomics: their results are here
+                    if (f_n) flush_store();                        // the image write above waited for this tile's rows, which
+                                                                   // were issued after the atomics: their results are here
                     finish_rows(it + DEPTH, pend_row[D], pend_bw[D], pend_nrm[D]);
                     start_rows(dsc_a[D], pend_row[D], pend_bw[D], pend_nrm[D]);
                     dsc_a[D] = fetch_desc(it + 3 * DEPTH);
                 }
                 lds_barrier();
-                if constexpr (S == 0 && !SAMPLE) {
-                    if (!f_n && p_tail - p_head >= 64u) flush_issue();
+                if constexpr (S == 0) {
+                    if (!f_n && p_tail - p_head >= 64u * FL_R) flush_issue();
                 }
                 issue(dc, sc, it + DEPTH);                         // in flight under the work of DEPTH whole tiles (past the
                                                                    // last tile: all slots invalid, row 0 from the cache)
@@ -395,62 +439,54 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
                 }
                 if (__ballot(pmask != 0) != 0) {                   // wave-uniform
                     if constexpr (SAMPLE) {
-                        if (pmask) {
-                            const uint32_t n = (uint32_t) __popc(pmask);
-                            const uint32_t base = atomicAdd(my_cnt, n);        // the count keeps growing past capq: overflow shows
+                        // The seed only needs the SMALLEST sampled values of a query, so a lane contributes the minimum of
+                        // its valid pairs (1 entry per 4 * NS rows; `fine` passes) or the four row-quad lanes of a query
+                        // column reduce theirs to one (1 entry per 16 * NS rows).  The m-th smallest of any subset of
+                        // the sample is >= the m-th smallest of the whole sample: the threshold only gets looser.
+                        uint64_t best = KEY_EMPTY;
 #pragma unroll
-                            for (int j = 0; j < NS * 4; ++j)
-                                if (pmask & (1u << j)) {           // value and key are (re)built for survivors only
-                                    const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
-                                    const uint32_t at = base + (uint32_t) __popc(pmask & ((1u << j) - 1u));
-                                    const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
-                                    if (at < p.capq) my_cand[at] = make_key(v, g_rank ? g_rank[ridx[slot]] : (uint32_t) ridx[slot]);
-                                }
+                        for (int j = 0; j < NS * 4; ++j) {
+                            const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
+                            const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
+                            const uint64_t key = make_key(v, (uint32_t) ridx[slot]);
+                            best = ((pmask >> j) & 1u) && key < best ? key : best;
                         }
+                        if (!sample_fine) {
+                            uint64_t o = __shfl_xor(best, 16);
+                            best = o < best ? o : best;
+                            o = __shfl_xor(best, 32);
+                            best = o < best ? o : best;
+                            if (kq != 0) best = KEY_EMPTY;
+                        }
+                        park(best != KEY_EMPTY, (uint32_t) (best >> 32), (uint32_t) best);
                     } else {
                         // one round per survivor of the busiest lane (1 - 2 at the usual ~1 % admission) instead of a
                         // predicated body per result register: the parking position is the wave's running count (wave
                         // uniform, in a scalar register) plus the lane's rank among the lanes of this round
-                        uint64_t act = __ballot(pmask != 0);
-                        while (act) {
-                            const uint32_t room = MW_PEND - (p_tail - p_head);
-                            if (pmask) {
-                                const int j = __builtin_ctz(pmask);
-                                pmask &= pmask - 1u;
-                                const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
-                                float a;                           // acc[j >> 2][j & 3] by a select tree on the bits of j
-                                if constexpr (NS == 1) {
-                                    const float b0 = j & 1 ? acc[0][1] : acc[0][0], b1 = j & 1 ? acc[0][3] : acc[0][2];
-                                    a = j & 2 ? b1 : b0;
-                                } else {
-                                    float c[NS];
+                        while (__ballot(pmask != 0)) {
+                            const bool has = pmask != 0;
+                            const int j = has ? __builtin_ctz(pmask) : 0;
+                            pmask &= pmask - 1u;                   // (0 stays 0)
+                            const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
+                            float a;                               // acc[j >> 2][j & 3] by a select tree on the bits of j
+                            if constexpr (NS == 1) {
+                                const float b0 = j & 1 ? acc[0][1] : acc[0][0], b1 = j & 1 ? acc[0][3] : acc[0][2];
+                                a = j & 2 ? b1 : b0;
+                            } else {
+                                float c[NS];
 #pragma unroll
-                                    for (int i = 0; i < NS; ++i) {
-                                        const float b0 = j & 1 ? acc[i][1] : acc[i][0], b1 = j & 1 ? acc[i][3] : acc[i][2];
-                                        c[i] = j & 2 ? b1 : b0;
-                                    }
-                                    if constexpr (NS == 2) a = j & 4 ? c[1] : c[0];
-                                    else {
-                                        const float d0 = j & 4 ? c[1] : c[0], d1 = j & 4 ? c[3] : c[2];
-                                        a = j & 8 ? d1 : d0;
-                                    }
+                                for (int i = 0; i < NS; ++i) {
+                                    const float b0 = j & 1 ? acc[i][1] : acc[i][0], b1 = j & 1 ? acc[i][3] : acc[i][2];
+                                    c[i] = j & 2 ? b1 : b0;
                                 }
-                                const float v = screen_value<METRIC>(a, rnrm[slot], my_qn);
-                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (act >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t) act, 0u));
-                                if (rank < room) {
-                                    const uint32_t at = (p_tail + rank) % MW_PEND;
-                                    pend_v[at] = v;
-                                    pend_r[at] = (uint32_t) ridx[slot];
-                                    pend_s[at] = my_slot;
-                                } else {                           // the wave's parking ring is full (a burst): reserve directly
-                                    const uint32_t ga = atomicAdd(my_cnt, 1u);
-                                    if (ga < p.capq) my_cand[ga] = make_key(v, g_rank ? g_rank[ridx[slot]] : (uint32_t) ridx[slot]);
+                                if constexpr (NS == 2) a = j & 4 ? c[1] : c[0];
+                                else {
+                                    const float d0 = j & 4 ? c[1] : c[0], d1 = j & 4 ? c[3] : c[2];
+                                    a = j & 8 ? d1 : d0;
                                 }
                             }
-                            const uint32_t n_act = (uint32_t) __popcll(act);
-                            p_tail += n_act < room ? n_act : room;
-                            act = __ballot(pmask != 0);
+                            const float v = screen_value<METRIC>(a, rnrm[slot], my_qn);
+                            park(has, mono_bits(v), (uint32_t) ridx[slot]);
                         }
                     }
                 }
@@ -468,12 +504,10 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     if (rsplit == 4) run(std::integral_constant<int, 1>{});
     else if (rsplit == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 4>{});
-    if constexpr (!SAMPLE) {                                                   // drain the parking ring
-        if (f_n) flush_store();
-        while (p_tail != p_head) {
-            flush_issue();
-            flush_store();
-        }
+    if (f_n) flush_store();                                                    // drain the parking ring
+    while (p_tail != p_head) {
+        flush_issue();
+        flush_store();
     }
 
     if (bad_row) atomicOr(p.err, 1u);                                          // a tile reached past the corpus: results invalid

@@ -124,6 +124,7 @@ struct vsr_ctx {
     DevBuf d_qcnt;       // K2w: [candidate counts | sample counts]
     bool   seeding = true;        // seed thresholds of big shared passes from a 1/32 sample pass
     int64_t seed_min_rows = 2000000;
+    uint32_t sample_stride = 16;  // K2w sample launch: every 16th tile of a workgroup (VSR_SAMPLE_STRIDE)
     int64_t seed_min_pass_rows = 2048;   // average rows per pass below which the warm-up it removes is too small to pay
     int32_t* d_flag_total = nullptr;   // running count of flagged queries (device)
     bool   screening = true;      // allow K2 (MFMA screening + exact re-rank) for shared passes
@@ -302,6 +303,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_NO_XCD_MAP"))) ctx->no_xcd_map = atoi(env) != 0;
     if ((env = getenv("VSR_MIN_SHARED_ROWS"))) ctx->min_shared_rows = std::max(64, atoi(env));
     if ((env = getenv("VSR_SEED_MIN_PASS"))) ctx->seed_min_pass_rows = atoll(env);
+    if ((env = getenv("VSR_SAMPLE_STRIDE"))) ctx->sample_stride = (uint32_t) std::min(512, std::max(2, atoi(env)));
     if ((env = getenv("VSR_SEED_STRIDE"))) SEED_STRIDE = (uint32_t) std::max(2, atoi(env));
     if ((env = getenv("VSR_SEED_DIV"))) SEED_BLOCK_DIV = (uint32_t) std::max(1, atoi(env));
     if ((env = getenv("VSR_NO_SCREENING"))) ctx->screening = atoi(env) == 0;
@@ -1220,7 +1222,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
             seed_div = std::max<uint32_t>(seed_div, (uint32_t) (budget / (2 * cus)));
         }
     }
-    if (plan.k2w) seed_div = std::max<uint32_t>(seed_div, 8);     // the sample launch: few workgroups, several tiles each
+    if (plan.k2w) seed_div = 1;                                   // the sample launch: the same workgroups, every ss-th tile
 
     // blocks per pass, then the partial lists of every query as CSR (count, prefix, fill): no per-query vectors
     static thread_local std::vector<uint32_t> loff, lcur, lids, lids_s;
@@ -1295,36 +1297,59 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     }
     if (plan.k2w) {
         // K2w keeps one candidate buffer per query: no partial lists, no K5 items.  What the plan still owes is the
-        // threshold seeding: the sample launch visits every 128th tile of each (sample) workgroup, at least one, so every
-        // pass is sampled at a fraction f >= 1/128 of its rows; the m-th best sampled key of a query, m = lambda + 6 sigma
-        // + 4 with lambda = kp * f for the DENSEST pass (a larger m only loosens the threshold), admits about m / f rows:
-        // kp + 6 sqrt(kp / f) + 4 / f <= ~1700 for f >= 1/128, inside the GQ_CAP keys a query's buffer holds.  A query
-        // whose sample is too thin to reach rank m gets an open threshold; that is only safe when all of its rows fit.
-        plan.sample_stride = 128;
-        static thread_local std::vector<double> est;
-        est.assign((size_t) nq, 0.0);
-        double frac = 1.0 / plan.sample_stride;
+        // threshold seeding.  The sample launch runs the same workgroups over every ss-th tile of theirs (at least one
+        // each), so every pass is sampled at a fraction f >= 1/ss of its rows, and keeps per query only minima: one
+        // entry per query column and wave-tile, or one per lane where a query's sample would otherwise be too thin
+        // (`fine` passes).  The seed is the m-th smallest entry of a query, m = lambda + 6 sqrt(lambda) + 4 with
+        // lambda = kp * f for the most densely sampled pass: more than m of the true top kp rows in the sample has
+        // probability ~1e-8, so the seed ranks behind the kp-th row and admits about m / f rows of the query:
+        // kp + 6 sqrt(kp / f) + 4 / f (~600 at f = 1/16, kp = 200).  Dropping sample entries (minima, buffer
+        // overflow) can only raise the m-th smallest, i.e. loosen the seed.  A query whose sample cannot reach rank m
+        // gets an open threshold; that is only safe when all of its rows fit its candidate buffer (GQ_CAP).
+        plan.sample_stride = ctx->sample_stride;
+        const double ss = plan.sample_stride;
+        double frac = 1.0 / ss;
         for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
             const ScanGroup& gs = plan.groups_s[gi];
-            const double rows = (double) gs.n_tiles * c->shape.rw;
-            const double t64 = std::ceil(rows / 64.0);
+            const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / 64.0);
             const double per_block = std::ceil(t64 / gs.n_blocks);
-            const double sampled = std::min(rows, gs.n_blocks * std::ceil(per_block / plan.sample_stride) * 64.0);
-            if (rows > 0) frac = std::max(frac, std::min(1.0, sampled / rows));
-            for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * gdens[gi];
+            const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
+            if (t64 > 0) frac = std::max(frac, sampled / t64);
         }
         const double lambda = (double) keep * frac;
         const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
         plan.kp_frac = (float) lambda;
         bool ok = seed_m <= GQ_SAMPLE_CAP / 4;
+        // fine passes: any query whose per-column minima (one per 64 rows of a sampled tile) would be fewer than 4 m
+        static thread_local std::vector<double> est;
+        est.assign((size_t) nq, 0.0);
+        for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
+            ScanGroup& gs = plan.groups_s[gi];
+            bool fine = false;
+            for (uint32_t qi = 0; qi < gs.q_count; ++qi) {
+                const vsr_filter* f = fof(plan.q_slots[gs.q_begin + qi]);
+                const double allowed = f ? (double) f->allowed_rows : (double) c->n;
+                fine |= allowed / (64.0 * ss) < 4.0 * seed_m;
+            }
+            gs.partial_begin = fine ? 1u : 0u;                     // (K2w has no partial lists: the field carries the flag)
+            const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / 64.0);
+            const double per_block = std::ceil(t64 / gs.n_blocks);
+            const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
+            const uint32_t ngt = (gs.q_count + 15) / 16;
+            const double waves_per_col = ngt == 1 ? 4.0 : ngt == 2 ? 2.0 : 1.0;     // row split (vsr_mfmaw.h)
+            const double entries_per_tile = waves_per_col * (fine ? 4.0 : 1.0);
+            const double rows_per_entry = 64.0 / entries_per_tile;
+            const double p_entry = std::min(1.0, gdens[gi] * rows_per_entry);      // a bitmap may leave an entry without rows
+            for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * entries_per_tile * p_entry;
+        }
         plan.selq.resize((size_t) nq);
         for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
             const vsr_filter* f = fof(q);
             const int64_t allowed = f ? f->allowed_rows : c->n;
-            // the sample of a query must fit its buffer (a bigger filter would be seeded from a thin subset and admit more
-            // rows than its candidate buffer holds), and be thick enough to reach rank m unless all of its rows fit anyway
-            if (allowed > (int64_t) GQ_MAX_ROWS) ok = false;
-            if (allowed > (int64_t) GQ_CAP && est[q] < 2.0 * seed_m) ok = false;
+            // the sample must be thick enough to reach rank m (with a margin where a bitmap makes the count random),
+            // unless all of the query's rows fit its buffer anyway
+            const bool exact_count = !f || f->allowed_rows == f->scanned_rows;
+            if (allowed > (int64_t) GQ_CAP && est[q] < (exact_count ? 1.25 * seed_m + 8.0 : 2.0 * seed_m)) ok = false;
             SelectQuery sq;
             sq.ids_begin = 0;
             sq.n_lists = 0;
