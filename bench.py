@@ -20,9 +20,12 @@ With N > 1 the corpus is sharded by contiguous row range (strong scaling: total 
 shard and the per-rank top-k lists are all-gathered over RCCL and merged on the GPU.  Inputs (corpus, filters,
 queries) are resident in HBM when the timed region starts.
 
-roofline: the physical floor of the main scan launch is max(unique row bytes / 8 TB/s, 2 * d * (row, query) pairs /
-157.3 TFLOP/s of fp32 MFMA); `frac` = that floor / the launch's HIP-event duration, `bound` names the larger term.
-The pass-structure figure of round 1 (bytes of every pass, re-reads from L2 included) is kept as `pass_bytes_rate`.
+roofline: `achieved` = the rows the main scan launch covers, each counted ONCE, in the layout the kernel reads (K2w:
+the bf16 screening planes, 2 or 4 bytes per element, + 4 bytes of |row|^2; K1 / K2: the fp32 rows) / the launch's
+HIP-event duration, against 8 TB/s; `bound` is "mfma" only if the matrix-core floor (the products the kernel issues at
+the dense peak of their type) is the larger one.  `fp32_equivalent` prices the same rows at SURVEY 8(d)'s 4 bytes per
+element: a rate for comparison with an fp32 scan, not an HBM fraction.  `traffic` = HBM bytes per launch from a
+rocprofv3 PMC pass of this command (profiles/), when one is on file for the workload.
 
 No part of the timed path touches the CPU oracle; it is used only by the cpu_baseline leg (rank 0, N = 1) and for the
 parity spot-check of the GPU results on the same sample.
@@ -83,32 +86,55 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd).returncode)
 
 
+MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md); the fp32 MFMA peak is MFMA_F32_PEAK_TF
+
+
+def kernel_layout(kernel, dim):
+    """(bytes per row the launch reads, MFMA flops per (row, query) pair it issues, MFMA peak) for the launched kernel."""
+    if "K2w" in kernel:
+        if "HO=true" in kernel:          # hi-only bf16 planes, rows padded to whole 128-element stages; products xh*qh + xh*qm
+            d_pad = -(-dim // 128) * 128
+            return d_pad * 2 + 4, 2 * 2 * d_pad, MFMA_BF16_PEAK_TF
+        d_pad = -(-dim // 64) * 64       # hi + mid planes; products xh*qh + xh*qm + xm*qh
+        return d_pad * 4 + 4, 3 * 2 * d_pad, MFMA_BF16_PEAK_TF
+    d_pad = -(-dim // 4) * 4             # fp32 rows (K1 / K1m: VALU; K2: fp32 MFMA)
+    return d_pad * 4 + (4 if "K2" in kernel else 0), 2 * d_pad, MFMA_F32_PEAK_TF
+
+
 def roofline_of(st, dim, kernel, n_sess, alone=None):
-    """Honest floors of the dominant scan launch class from the library's statistics (HIP events on the launch stream)."""
+    """Floors of the dominant scan launch class from the library's statistics (HIP events on the launch stream).
+    `achieved` counts every row the launch scans ONCE, in the layout the kernel actually reads (the screening planes of
+    K2w are 2 or 4 bytes per element + 4 bytes of |row|^2): it cannot exceed what HBM delivers.  The same rows priced at
+    SURVEY 8(d)'s 4 bytes per element are reported beside it as `fp32_equivalent` (a rate, not an HBM fraction)."""
     cls = int(np.argmax(st["scan_ms"]))
     launches = max(1, st["scan_launches"][cls])
     ms = st["scan_ms"][cls] / launches
-    pass_bytes = st["scan_bytes"][cls] / launches
     pairs = st["scan_pairs"][cls] / launches
-    unique_bytes = st["unique_rows"][cls] / launches * dim * 4
-    flops = 2.0 * dim * pairs
-    t_hbm, t_mfma = unique_bytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
+    rows = st["unique_rows"][cls] / launches
+    row_bytes, pair_flops, mfma_peak = kernel_layout(kernel, dim)
+    unique_bytes = rows * row_bytes
+    fp32_bytes = rows * dim * 4
+    flops = pair_flops * pairs
+    t_hbm, t_mfma = unique_bytes / (HBM_PEAK_GBS * 1e9), flops / (mfma_peak * 1e12)
     sec = ms * 1e-3
 
     def floors(seconds):
         if t_hbm >= t_mfma:
             return "hbm", unique_bytes / seconds / 1e9, HBM_PEAK_GBS, "GB/s"
-        return "mfma", flops / seconds / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+        return "mfma", flops / seconds / 1e12, mfma_peak, "TFLOP/s"
 
     bound, achieved, peak, unit = floors(sec) if sec > 0 else ("hbm", 0.0, HBM_PEAK_GBS, "GB/s")
     r = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
          "traffic": None, "kernel": kernel, "launch_ms": round(ms, 4), "launches": int(launches),
-         "unique_bytes": int(unique_bytes), "flops": int(flops),
-         "floor_ms": {"hbm_8TBs": round(t_hbm * 1e3, 4), "mfma_f32_157TF": round(t_mfma * 1e3, 4)},
-         "hbm_frac_unique_bytes": round(unique_bytes / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
-         "mfma_frac": round(flops / sec / 1e12 / MFMA_F32_PEAK_TF, 4) if sec > 0 else 0.0,
-         "pass_bytes_per_launch": int(pass_bytes),
-         "pass_bytes_rate": round(pass_bytes / sec / 1e9, 1) if sec > 0 else 0.0,
+         "unique_rows": int(rows), "row_bytes": row_bytes, "unique_bytes": int(unique_bytes),
+         "floor_ms": {"hbm_8TBs": round(t_hbm * 1e3, 4), f"mfma_{mfma_peak:g}TF": round(t_mfma * 1e3, 4)},
+         "mfma": {"flops_issued": int(flops), "peak_tflops": mfma_peak,
+                  "frac": round(flops / sec / 1e12 / mfma_peak, 4) if sec > 0 else 0.0},
+         "fp32_equivalent": {"unique_bytes": int(fp32_bytes), "rate_gbs": round(fp32_bytes / sec / 1e9, 1) if sec > 0 else 0.0,
+                             "flops": int(2.0 * dim * pairs),
+                             "note": "the same rows at 4 bytes per element (SURVEY 8d) and 2*d flops per pair: what an "
+                                     "fp32 scan would have to move / compute for this step; not an HBM fraction"},
+         "pass_rows_per_launch": int(st["scan_rows"][cls] / launches),
          "all_scan_ms": [round(v, 3) for v in st["scan_ms"]]}
     if n_sess > 1:
         r["note"] = (f"{n_sess} batches in flight: a launch's event-timed duration includes the time it shares the GPU "
@@ -394,7 +420,6 @@ def main():
     def leg_record(leg, r):
         dt = r["dt"]
         roof = roofline_of(r["stats"], dim, r["kernel"], state["n_sess"], r["alone"])
-        roof["wall_pass_bytes_rate"] = round(sum(r["stats"]["scan_bytes"]) / dt / 1e9, 1)
         tag = f"{n}x{dim} k={k} q={nq} {leg} gpus={world}"
         try:      # HBM bytes per launch from a PMC pass of this same command (never measured inside the timed run)
             with open(args.traffic) as f:
@@ -403,7 +428,9 @@ def main():
             if ent:
                 short = r["kernel"].split("<")[0].replace("vsr::", "")
                 for name, v in ent["kernels"].items():
-                    if short in name and ", true," not in name:          # the main launch, not the SAMPLE=true pass
+                    targs = name.split("<", 1)[1].split(">", 1)[0].replace(" ", "").split(",") if "<" in name else []
+                    is_sample = short == "mfma_wide_kernel" and len(targs) > 2 and targs[2] == "true"
+                    if short in name and not is_sample:                  # the main launch, not the SAMPLE=true pass
                         roof["traffic"] = int(v["hbm_bytes_per_launch"])
                         roof["traffic_source"] = os.path.relpath(args.traffic, ROOT) + ": " + tr.get("method", "")
                         roof["hbm_rate_measured"] = round(roof["traffic"] / (roof["launch_ms"] * 1e-3) / 1e9, 1)

@@ -5,7 +5,7 @@ Per MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB (hbm_bytes = (
 on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so the
 read side is doubled; WRITE_SIZE is exact.  The two counters need separate passes (TCC slots).
 
-  python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> [workload-tag]
+  python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> <workload-tag>
 """
 import csv
 import glob
@@ -40,9 +40,15 @@ def main():
             "hbm_write_bytes_per_launch": w * 1024,
             "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
         }
-    json.dump({"workload": tag, "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
-               "KiB units, FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)", "kernels": kernels},
-              open(out, "w"), indent=1)
+    # one file per round, one entry per workload tag (bench.py looks its own tag up: "<rows>x<dim> k=.. q=.. <leg> gpus=N")
+    doc = {}
+    if os.path.exists(out):
+        with open(out) as fh:
+            doc = json.load(fh)
+    doc["method"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB units, FETCH_SIZE x2 on gfx950 "
+                     "(MI355X_MICROARCH.md, HBM)")
+    doc[tag] = {"kernels": kernels}
+    json.dump(doc, open(out, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{v['hbm_bytes_per_launch'] / 1e9:10.3f} GB/launch  x{v['dispatches']:<4d} {k[:90]}")
 
