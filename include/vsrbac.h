@@ -147,11 +147,22 @@ int vsr_search_device_on(vsr_ctx* session, vsr_corpus* corpus, const float* d_qu
                          int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows,
                          float* d_out_dist, int32_t* d_out_counts, uint64_t* d_out_keys);
 
-/* Shared passes of L2 / inner-product / cosine searches may run on the matrix cores: an fp32-MFMA screening keeps
- * 2k candidates per query and an exact re-rank reports the k best.  The re-rank flags a
- * query when the screening's rounding error could have excluded a true result; vsr_search re-runs flagged queries on
- * the exact path itself.  After vsr_search_device the caller checks: flagged_total = flagged queries since vsr_open,
- * flags_last_call[i] != 0 = query i of the last call must be re-run with screening disabled.  Synchronises. */
+/* same as vsr_search_device_on, but the call returns only when every query is PROVEN exact: it waits for the search,
+ * and queries the screening flagged (below) are re-run on the exact path and patched into the outputs, all on the
+ * session's stream.  n_rerun (may be NULL) receives how many queries that took.  Synchronises the session's stream. */
+int vsr_search_device_exact(vsr_ctx* session, vsr_corpus* corpus, const float* d_queries, int nq, int dim, int k, int metric,
+                            const vsr_filter* const* filters,
+                            int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows,
+                            float* d_out_dist, int32_t* d_out_counts, uint64_t* d_out_keys, int32_t* n_rerun);
+
+/* Flagged queries.  Shared passes of L2 / inner-product / cosine searches may run on the matrix cores: a bf16 / fp32
+ * MFMA screening with sampled thresholds keeps 2k candidates per query and an exact re-rank reports the k best (see
+ * DESIGN.md, K2w / K5r).  The re-rank FLAGS a query when the screening's rounding error or a too-tight threshold could
+ * have excluded a true result (rare: none in the benchmark's 3 M queries).  A flagged query cannot be mistaken for a
+ * result: its out_counts entry is NEGATIVE (-1 - rows written).  vsr_search and vsr_search_device_exact re-run
+ * flagged queries themselves.  After the asynchronous vsr_search_device(_on) the caller either tests the counts on the
+ * device or calls vsr_screening_check: flagged_total = flagged queries since vsr_open, flags_last_call[i] != 0 =
+ * query i of the last call must be re-run with screening disabled.  vsr_screening_check synchronises. */
 int vsr_set_screening(vsr_ctx* ctx, int enable);           /* default: enabled; 0 also disables threshold seeding, so
                                                               searches of that context are exact and never flag */
 int vsr_screening_check(vsr_ctx* ctx, int64_t* flagged_total, int32_t* flags_last_call, int nq);

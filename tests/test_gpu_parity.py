@@ -10,6 +10,8 @@ import json
 import math
 import os
 
+from types import SimpleNamespace
+
 import numpy as np
 import pytest
 
@@ -187,6 +189,45 @@ def test_screening_gap_inside_error_bound_falls_back_to_exact(ctx, oracle):
     ctx.set_screening(True)
     assert ctx.screening_check(0)[0] == after
     np.testing.assert_array_equal(res2.rows, res.rows)
+    corpus.free()
+
+
+def test_device_api_flags_cannot_be_ignored_and_exact_variant_reruns(ctx, oracle):
+    """vsr_search_device is asynchronous and cannot re-run anything itself: a flagged query reports a NEGATIVE count
+    (-1 - rows), so a caller that never calls vsr_screening_check still cannot publish its rows as a result.
+    vsr_search_device_exact waits, re-runs the flagged queries on the exact path and patches the outputs."""
+    import torch
+    rng = np.random.default_rng(12)
+    base = sift_like(rng, 8)
+    x = np.repeat(base, 300, axis=0)                     # every vector 300 times: ties far beyond 2k = 200
+    x = x[rng.permutation(x.shape[0])]
+    n = x.shape[0]
+    blk = (rng.permutation(n) + 1).astype(np.int64)
+    doc = rng.integers(1, 20, n).astype(np.int32)
+    corpus = ctx.load_corpus(x, blk, doc)
+    dev = torch.device("cuda", 0)
+    nq, k = 6, 100
+    q = torch.from_numpy(base[:nq].copy()).to(dev)
+    o_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    o_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    o_row = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    o_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    args = (o_blk.data_ptr(), o_doc.data_ptr(), o_row.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr())
+    corpus.search_device(q.data_ptr(), nq, k, "l2", None, *args)
+    _, flags = ctx.screening_check(nq)                   # synchronises
+    cnt = o_cnt.cpu().numpy()
+    assert flags.any(), "the tie-saturated queries should have been flagged"
+    assert ((cnt < 0) == (flags != 0)).all(), (cnt, flags)
+    assert (cnt[flags != 0] == -1 - k).all()
+    n_rerun = corpus.search_device_exact(q.data_ptr(), nq, k, "l2", None, *args)
+    assert n_rerun == int((flags != 0).sum())
+    cnt = o_cnt.cpu().numpy()
+    assert (cnt == k).all()
+    res = SimpleNamespace(block_ids=o_blk.cpu().numpy(), doc_ids=o_doc.cpu().numpy(), rows=o_row.cpu().numpy(),
+                          dist=o_dist.cpu().numpy(), counts=cnt)
+    for i in range(nq):
+        _expect_exact(oracle, res, i, "l2", x, base[i], k, doc, blk)
     corpus.free()
 
 

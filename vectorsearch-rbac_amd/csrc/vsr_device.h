@@ -55,6 +55,29 @@ struct ScanGroup {
     uint32_t        partial_begin; // partial list index = partial_begin + qi * n_blocks + local_block
 };
 
+// nq == 1 fast path (the reference's own call shape: one query per call): the whole search in ONE launch.  K1 scans,
+// every workgroup publishes its k best, and the LAST workgroup of every group of `fan` (a counter, no waiting) merges
+// the group's lists, the last of those merges the merged lists and writes the caller's rows.  No staging kernel (the one
+// pass travels in the kernel arguments, the query is read where the caller put it), no selection launch.
+struct FusedTail {
+    uint32_t        enable;
+    uint32_t        fan;           // workgroups per first-level merge
+    ScanGroup       group;         // the single pass
+    uint32_t*       done;          // [1 + groups] arrival counters; zero between calls
+    const int64_t*  block_ids;
+    const int32_t*  doc_ids;
+    const int64_t*  orig_rows;
+    int64_t*        out_block;
+    int32_t*        out_doc;
+    int64_t*        out_row;       // may be nullptr
+    float*          out_dist;
+    uint64_t*       out_keys;      // may be nullptr
+    int32_t*        out_count;
+    int32_t*        out_flag;      // the call's flag word (the exact path never flags: cleared)
+    uint32_t        row_offset;
+    int             metric;
+};
+
 struct ScanParams {
     const float4*    rows;         // [n_rows][stride4] row-major, zero padded
     const float*     norm2;        // [n_rows] sum x^2 (cosine)
@@ -89,6 +112,7 @@ struct ScanParams {
                                    // identity.  Set for list-ordered views (IVF): see vsr_corpus::base
     const uint64_t*  ones;         // one all-ones 64-bit word (the "bitmap" of passes without a permission bitmap)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
+    FusedTail        fused;        // K1, nq == 1 only (enable = 0 otherwise)
 };
 
 // Per query: which partial lists to merge and where to put the result.

@@ -168,8 +168,11 @@ __device__ __forceinline__ void select_emit(const SelectParams& p, const SelectQ
         }
     }
     if (tid == 0) {
-        p.out_count[sq.out_slot] = (int32_t) m;
-        if (p.seeded && m < k && m < sq.allowed) {           // a seeded threshold cut below the k-th result
+        const bool flag = p.seeded && m < k && m < sq.allowed;   // a seeded threshold cut below the k-th result
+        // a flagged query reports its count as -1 - count: a caller that never looks at the flags still cannot take
+        // the unproven rows for a result (include/vsrbac.h, "flagged queries")
+        p.out_count[sq.out_slot] = flag ? -1 - (int32_t) m : (int32_t) m;
+        if (flag) {
             p.out_flags[sq.out_slot] = 1;
             atomicAdd(p.flagged_total, 1);
         }
@@ -855,6 +858,7 @@ __device__ __forceinline__ void rerank_body(const RerankParams& p, uint32_t slot
 
     // how many exact keys exist, and the flag
     __shared__ uint32_t s_count;
+    __shared__ int s_flag;
     if (tid == 0) {
         uint32_t lo = 0, hi = p.kp < np2 ? p.kp : np2;
         while (lo < hi) {
@@ -884,6 +888,7 @@ __device__ __forceinline__ void rerank_body(const RerankParams& p, uint32_t slot
             }
         }
         p.out_flags[out_slot] = flag;
+        s_flag = flag;
         if (flag) atomicAdd(p.flagged_total, 1);
     }
     __syncthreads();
@@ -907,7 +912,7 @@ __device__ __forceinline__ void rerank_body(const RerankParams& p, uint32_t slot
             if (p.out_keys) p.out_keys[o + i] = KEY_EMPTY;
         }
     }
-    if (tid == 0) p.out_count[out_slot] = (int32_t) m;
+    if (tid == 0) p.out_count[out_slot] = s_flag ? -1 - (int32_t) m : (int32_t) m;    // flagged: -1 - count (see select_emit)
 }
 
 __global__ __launch_bounds__(256) void rerank_kernel(const RerankParams p)

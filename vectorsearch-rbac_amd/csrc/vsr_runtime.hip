@@ -122,6 +122,7 @@ struct vsr_ctx {
     DevBuf d_tau;        // seeded thresholds (sample pass)
     DevBuf d_samp;       // K2w: per-query sample buffers
     DevBuf d_qcnt;       // K2w: [candidate counts | sample counts]
+    bool   no_fused = false;      // VSR_NO_FUSED: nq == 1 takes the general path (staging, K1, K5)
     bool   seeding = true;        // seed thresholds of big shared passes from a 1/32 sample pass
     int64_t seed_min_rows = 2000000;
     uint32_t sample_stride = 16;  // K2w sample launch: every 16th tile of a workgroup (VSR_SAMPLE_STRIDE)
@@ -131,6 +132,8 @@ struct vsr_ctx {
     int64_t flagged_seen = 0;
     DevBuf d_out;        // host-API outputs
     DevBuf d_misc;
+    DevBuf d_done;                // nq == 1 fused path: arrival counters of the in-kernel merge tree (zero between calls)
+    DevBuf d_redo;                // vsr_search_device_exact: queries and results of the flagged queries
     PinBuf h_desc;
     PinBuf h_out;
     hipEvent_t desc_done = nullptr;   // staging buffer reuse guard
@@ -300,6 +303,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
+    if ((env = getenv("VSR_NO_FUSED"))) ctx->no_fused = atoi(env) != 0;
     if ((env = getenv("VSR_NO_XCD_MAP"))) ctx->no_xcd_map = atoi(env) != 0;
     if ((env = getenv("VSR_MIN_SHARED_ROWS"))) ctx->min_shared_rows = std::max(64, atoi(env));
     if ((env = getenv("VSR_SEED_MIN_PASS"))) ctx->seed_min_pass_rows = atoll(env);
@@ -1701,6 +1705,95 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     const uint32_t kp = plan.keep;
     const vsr_corpus* idc = c->base ? c->base : c;          // identity arrays and re-rank rows (c may be a list-ordered view)
     const size_t qfloats = (size_t) c->stride4 * 4;
+
+    // ---- one query, one pass: the whole search in ONE launch (FusedTail, vsr_device.h) ----
+    // conditions: the query already lies in device memory in the row layout (d a multiple of 4: no padding to add),
+    // no |q|^2 needed (not cosine), one plain pass on K1, k small enough for the workgroup's LDS top-k buffer
+    if (nq == 1 && !ctx->no_fused && plan.groups.size() == 1 && plan.qi == 1 && !plan.k2 && !plan.mq &&
+        dim % 4 == 0 && metric != VSR_METRIC_COSINE && plan.groups[0].n_blocks <= 64u * 64u && ctx->profiling != 1) {
+        const uint32_t cap = std::max<uint32_t>(4096, scan_cap_for_k((int) kp, c->dim));   // the merge's LDS layout (vsr_scan.h, FUSED_*)
+        const ScanGroup& g = plan.groups[0];
+        const uint32_t per_merge = kp ? 8192u / kp : 0u;    // lists one merge takes (16 keys per thread, vsr_scan.h)
+        const uint32_t fan = per_merge ? std::max<uint32_t>(16, (g.n_blocks + per_merge - 1) / per_merge) : 0u;
+        if (kp <= 512 && fan && fan <= per_merge) {
+            int rc;
+            const uint32_t n_g = (g.n_blocks + fan - 1) / fan;
+            if ((rc = ctx->d_partial.reserve((size_t) (g.n_blocks + n_g) * kp * sizeof(uint64_t)))) return rc;
+            if ((rc = ctx->d_flags.reserve(sizeof(int32_t)))) return rc;
+            if (!ctx->d_done.p) {
+                if ((rc = ctx->d_done.reserve((size_t) (1 + 4096 / 16 + 64) * sizeof(uint32_t)))) return rc;
+                HIPCHK(hipMemsetAsync(ctx->d_done.p, 0, ctx->d_done.cap, ctx->stream));
+            }
+            const float* q_dev = d_queries;
+            if (!q_dev) {
+                // host query: the kernel reads it straight out of the pinned staging block (512 bytes, cached after the
+                // first workgroup), which the previous call's kernel must have left
+                if (ctx->desc_pending) {
+                    HIPCHK(hipEventSynchronize(ctx->desc_done));
+                    ctx->desc_pending = false;
+                }
+                if ((rc = ctx->h_desc.reserve(qfloats * sizeof(float)))) return rc;
+                memcpy(ctx->h_desc.p, h_queries, (size_t) dim * sizeof(float));
+                q_dev = reinterpret_cast<const float*>(ctx->h_desc.dp);
+            }
+            ScanParams sp{};
+            sp.rows = c->d_rows;
+            sp.norm2 = c->d_norm2;
+            sp.n_rows = (uint32_t) c->n;
+            sp.stride4 = c->stride4;
+            sp.queries = q_dev;
+            sp.partial = ctx->d_partial.as<uint64_t>();
+            sp.kp = sp.k = kp;
+            sp.cap = cap;
+            sp.qmax = 1;
+            sp.rw = (uint32_t) c->shape.rw;
+            sp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;
+            sp.ones = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(ctx->d_flag_total) + 32);
+            sp.rank = c->d_rank;
+            sp.sample_stride = 1;
+            sp.n_groups = 1;
+            sp.fused.enable = 1;
+            sp.fused.fan = fan;
+            sp.fused.group = g;
+            sp.fused.group.block_begin = 0;
+            sp.fused.group.partial_begin = 0;
+            sp.fused.done = ctx->d_done.as<uint32_t>();
+            sp.fused.block_ids = idc->d_block;
+            sp.fused.doc_ids = idc->d_doc;
+            sp.fused.orig_rows = idc->d_orig;
+            sp.fused.out_block = d_blk;
+            sp.fused.out_doc = d_doc;
+            sp.fused.out_row = d_row;
+            sp.fused.out_dist = d_dist;
+            sp.fused.out_keys = d_keys;
+            sp.fused.out_count = d_cnt;
+            sp.fused.out_flag = ctx->d_flags.as<int32_t>();
+            sp.fused.row_offset = (uint32_t) idc->row_offset;
+            sp.fused.metric = metric;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ctx->profiling) {
+                e0 = take_event(ctx);
+                e1 = take_event(ctx);
+                HIPCHK(hipEventRecord(e0, ctx->stream));
+            }
+            HIPCHK(launch_scan(sp, metric, c->dim, 1, g.n_blocks, ctx->stream));
+            if (!d_queries) {
+                HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
+                ctx->desc_pending = true;
+            }
+            if (e0) {
+                HIPCHK(hipEventRecord(e1, ctx->stream));
+                ctx->pending.push_back({e0, e1, 0});
+            }
+            ctx->last_kernel = scan_kernel_name(plan, c, metric) + " + in-kernel merge";
+            ctx->stats.scan_bytes[0] += plan.scan_bytes;
+            ctx->stats.scan_rows[0] += plan.scan_rows;
+            ctx->stats.scan_pairs[0] += plan.scan_pairs;
+            ctx->stats.unique_rows[0] += plan.unique_rows;
+            ctx->stats.queries += 1;
+            return VSR_OK;
+        }
+    }
     // one staging block: [queries | q_norm2 | scan groups | sample groups | pass query slots | K5 items | list ids]
     const size_t off_q = 0;
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
@@ -2003,6 +2096,63 @@ extern "C" int vsr_search_device(vsr_corpus* c, const float* d_queries, int nq, 
 {
     return vsr_search_device_on(nullptr, c, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt,
                                 d_keys);
+}
+
+// The device API for callers that cannot tolerate an unproven row: search, wait, re-run what was flagged, patch.
+extern "C" int vsr_search_device_exact(vsr_ctx* session, vsr_corpus* c, const float* d_queries, int nq, int dim, int k,
+                                       int metric, const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc,
+                                       int64_t* d_row, float* d_dist, int32_t* d_cnt, uint64_t* d_keys, int32_t* n_rerun)
+{
+    if (n_rerun) *n_rerun = 0;
+    int rc = vsr_search_device_on(session, c, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys);
+    if (rc || nq == 0) return rc;
+    vsr_ctx* ctx = session ? session : c->ctx;
+    std::vector<int32_t> flags((size_t) nq, 0);
+    HIPCHK(hipMemcpyAsync(flags.data(), ctx->d_flags.p, (size_t) nq * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<int> redo;
+    for (int i = 0; i < nq; ++i)
+        if (flags[(size_t) i]) redo.push_back(i);
+    if (redo.empty()) return VSR_OK;
+    ctx->flagged_seen += (int64_t) redo.size();
+    const size_t nr = redo.size(), nk = nr * (size_t) k;
+    // workspace: [queries | block | row | doc | dist | keys | counts] of the flagged queries
+    const size_t o_q = 0, o_blk = align_up(o_q + nr * (size_t) dim * 4, 256), o_row = align_up(o_blk + nk * 8, 256),
+                 o_doc = align_up(o_row + nk * 8, 256), o_dist = align_up(o_doc + nk * 4, 256),
+                 o_key = align_up(o_dist + nk * 4, 256), o_cnt = align_up(o_key + nk * 8, 256),
+                 total = align_up(o_cnt + nr * 4, 256);
+    if ((rc = ctx->d_redo.reserve(total))) return rc;
+    char* w = ctx->d_redo.as<char>();
+    std::vector<const vsr_filter*> f2(nr, nullptr);
+    for (size_t j = 0; j < nr; ++j) {
+        HIPCHK(hipMemcpyAsync(w + o_q + j * (size_t) dim * 4, d_queries + (size_t) redo[j] * dim, (size_t) dim * 4,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+        if (filters) f2[j] = filters[redo[j]];
+    }
+    rc = search_impl(ctx, c, nullptr, reinterpret_cast<const float*>(w + o_q), (int) nr, dim, k, metric, f2.data(),
+                     reinterpret_cast<int64_t*>(w + o_blk), reinterpret_cast<int32_t*>(w + o_doc),
+                     reinterpret_cast<int64_t*>(w + o_row), reinterpret_cast<float*>(w + o_dist),
+                     reinterpret_cast<int32_t*>(w + o_cnt), reinterpret_cast<uint64_t*>(w + o_key), false);
+    if (rc) return rc;
+    for (size_t j = 0; j < nr; ++j) {
+        const size_t src = j * (size_t) k, dst = (size_t) redo[j] * k;
+        auto patch = [&](void* to, const void* from, size_t bytes) {
+            return hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+        };
+        HIPCHK(patch(d_blk + dst, reinterpret_cast<int64_t*>(w + o_blk) + src, (size_t) k * 8));
+        if (d_row) HIPCHK(patch(d_row + dst, reinterpret_cast<int64_t*>(w + o_row) + src, (size_t) k * 8));
+        if (d_doc) HIPCHK(patch(d_doc + dst, reinterpret_cast<int32_t*>(w + o_doc) + src, (size_t) k * 4));
+        HIPCHK(patch(d_dist + dst, reinterpret_cast<float*>(w + o_dist) + src, (size_t) k * 4));
+        if (d_keys) HIPCHK(patch(d_keys + dst, reinterpret_cast<uint64_t*>(w + o_key) + src, (size_t) k * 8));
+        HIPCHK(patch(d_cnt + redo[j], reinterpret_cast<int32_t*>(w + o_cnt) + j, 4));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // the exact path never flags; anything else is a library fault and must not be published
+    HIPCHK(hipMemcpy(flags.data(), ctx->d_flags.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t j = 0; j < nr; ++j)
+        if (flags[j]) return fail(VSR_ERR_HIP, "vsr_search_device_exact: query %d still flagged after the exact re-run", redo[j]);
+    if (n_rerun) *n_rerun = (int32_t) nr;
+    return VSR_OK;
 }
 
 // Host-buffer search on a corpus or on a list-ordered view of one: the search, then the exact re-run of flagged queries.

@@ -107,6 +107,209 @@ struct TileRegs {
     float4   x[R][CC];
 };
 
+// ---- nq == 1: in-kernel merge tree (FusedTail, vsr_device.h) ----
+constexpr int FUSED_KPT = 16;                               // keys per thread of one merge: <= 8192 keys
+constexpr uint32_t FUSED_CLS = 1024;                        // a tie class this small is ranked directly
+// LDS of a merge (in units of keys, inside the workgroup's top-k buffer of >= 4096 keys): the selected keys, the final
+// tie class, one digit histogram per wave, scalars
+constexpr uint32_t FUSED_OUT = 0, FUSED_CLS_AT = 512, FUSED_HIST_AT = 1536, FUSED_SC_AT = 2560;
+// The k smallest of up to SCAN_THREADS * 16 keys at `src` (global memory written by other workgroups of this launch:
+// device-scope loads) -> out[0 .. count) in LDS, unordered.  The keys sit in registers; an MSB-first radix select over
+// 8-bit digits (one histogram per wave in LDS, digits every key shares are skipped) narrows the class holding the k-th
+// key; as soon as that class has <= 1024 keys (SIFT's integer distances tie a lot, and ties are broken by the row id in
+// the low word: without this the select would walk all 8 digits) its keys are ranked directly.  No sorting network.
+// Returns count (same in every thread).
+template <bool LOCAL = false>                               // LOCAL: `src` is the workgroup's own LDS buffer (may alias `lds`)
+__device__ __forceinline__ uint32_t fused_block_select(const uint64_t* src, uint32_t n, uint32_t k, uint64_t* lds, int tid)
+{
+    uint64_t* out = lds + FUSED_OUT;
+    uint64_t* cls = lds + FUSED_CLS_AT;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds + FUSED_HIST_AT);         // [SCAN_WAVES][256]
+    uint64_t* sc = lds + FUSED_SC_AT;                                          // [0] min, [1] max
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(sc + 2);    // [0] real keys, [1] selected so far, [2] digit, [3] keys before it,
+                                                            // [4] population of the chosen bin, [5] class fill
+    const int wave = tid >> 6;
+    uint64_t reg[FUSED_KPT];
+#pragma unroll
+    for (int r = 0; r < FUSED_KPT; ++r) {
+        const uint32_t i = (uint32_t) (r * SCAN_THREADS + tid);
+        if constexpr (LOCAL) reg[r] = i < n ? src[i] : KEY_EMPTY;
+        else reg[r] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_EMPTY;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        sc[0] = KEY_EMPTY;
+        sc[1] = 0;
+        cnt[0] = cnt[1] = cnt[5] = 0;
+    }
+    __syncthreads();
+    {
+        uint64_t mn = KEY_EMPTY, mx = 0;
+        uint32_t real = 0;
+#pragma unroll
+        for (int r = 0; r < FUSED_KPT; ++r)
+            if (reg[r] != KEY_EMPTY) {
+                mn = reg[r] < mn ? reg[r] : mn;
+                mx = reg[r] > mx ? reg[r] : mx;
+                ++real;
+            }
+        // wave-level reduction first: one LDS atomic per wave, not per thread
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint64_t omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+            mn = omn < mn ? omn : mn;
+            mx = omx > mx ? omx : mx;
+            real += (uint32_t) __shfl_xor((int) real, d);
+        }
+        if ((tid & 63) == 0 && real) {
+            atomicMin(reinterpret_cast<unsigned long long*>(sc), (unsigned long long) mn);
+            atomicMax(reinterpret_cast<unsigned long long*>(sc + 1), (unsigned long long) mx);
+            atomicAdd(cnt, real);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_real = cnt[0];
+    uint64_t prefix = 0, mask = 0;                          // class of the k-th key: (key & mask) == prefix
+    uint32_t want = k, pop = n_real;                        // keys to take from the class / keys in it
+    if (n_real > k) {
+        const uint64_t diff = sc[0] ^ sc[1];
+        int shift = diff ? (63 - __builtin_clzll(diff)) / 8 * 8 : 0;           // first digit in which the keys differ
+        mask = shift >= 56 ? 0ull : ~0ull << (shift + 8);
+        prefix = sc[0] & mask;
+        while (pop > FUSED_CLS && pop != want) {
+            for (int i = tid; i < SCAN_WAVES * 256; i += SCAN_THREADS) hist[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < FUSED_KPT; ++r)
+                if (reg[r] != KEY_EMPTY && (reg[r] & mask) == prefix)
+                    atomicAdd(&hist[wave * 256 + ((uint32_t) (reg[r] >> shift) & 255u)], 1u);
+            __syncthreads();
+            if (tid < 64) {                                 // wave 0: the bin holding the want-th key of the class
+                uint32_t h[4], sum = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = 0;
+#pragma unroll
+                    for (int w = 0; w < SCAN_WAVES; ++w) h[j] += hist[w * 256 + tid * 4 + j];
+                    sum += h[j];
+                }
+                uint32_t incl = sum;                        // inclusive prefix sum over the lanes
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = (uint32_t) __shfl_up((int) incl, d);
+                    if (tid >= d) incl += o;
+                }
+                uint32_t before = incl - sum;
+                if (before < want && want <= incl) {        // exactly one lane
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (before < want && want <= before + h[j]) {
+                            cnt[2] = (uint32_t) (tid * 4 + j);
+                            cnt[3] = before;
+                            cnt[4] = h[j];
+                        }
+                        before += h[j];
+                    }
+                }
+            }
+            __syncthreads();
+            prefix |= (uint64_t) cnt[2] << shift;
+            mask |= 0xFFull << shift;
+            want -= cnt[3];
+            pop = cnt[4];
+            shift -= 8;                                     // (keys are unique: pop reaches 1 at the last digit at the latest)
+            __syncthreads();                                // everybody has read cnt before the next round rewrites it
+        }
+    }
+    // everything below the class is selected; the class itself entirely, or its `want` smallest by direct ranking
+    const bool rank_class = n_real > k && pop != want;
+#pragma unroll
+    for (int r = 0; r < FUSED_KPT; ++r) {
+        if (reg[r] == KEY_EMPTY) continue;
+        const uint64_t hi = reg[r] & mask;
+        if (n_real <= k || hi < prefix || (hi == prefix && !rank_class)) out[atomicAdd(cnt + 1, 1u)] = reg[r];
+        else if (hi == prefix) cls[atomicAdd(cnt + 5, 1u)] = reg[r];
+    }
+    __syncthreads();
+    if (rank_class) {
+        const uint32_t fill = cnt[5];                       // == pop <= FUSED_CLS
+        for (uint32_t j = (uint32_t) tid; j < fill; j += SCAN_THREADS) {
+            const uint64_t mine = cls[j];
+            uint32_t rank = 0;
+            for (uint32_t i = 0; i < fill; ++i) rank += cls[i] < mine;          // LDS broadcast reads
+            if (rank < want) out[atomicAdd(cnt + 1, 1u)] = mine;
+        }
+        __syncthreads();
+    }
+    return cnt[1];
+}
+
+__device__ __forceinline__ void fused_tail(const ScanParams& p, const ScanGroup& grp, uint32_t local_block, uint64_t* keys,
+                                        int tid)
+{
+    __shared__ uint32_t s_last;
+    const FusedTail& f = p.fused;
+    const uint32_t B = grp.n_blocks, fan = f.fan, n_g = (B + fan - 1) / fan, k = p.k, kp = p.kp;
+    const uint32_t my_g = local_block / fan;
+    const uint32_t g_size = (my_g + 1) * fan <= B ? fan : B - my_g * fan;
+    uint64_t* lists = p.partial + (size_t) grp.partial_begin * kp;            // [B] workgroup lists, then [n_g] merged lists
+    // Arrival.  The lists are exchanged with DEVICE-SCOPE stores and loads (write-through / cache-bypassing), not with
+    // __threadfence(): a device-scope release on this chip writes the whole L2 back, and a thousand workgroups doing
+    // that cost 0.3 ms.  __syncthreads() waits for the workgroup's stores to complete, so they are visible device-wide
+    // before the counter moves; the workgroup that sees the last arrival owns the merge.  Nobody ever waits: every
+    // workgroup but one per counter simply ends.
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(f.done + 1 + my_g, 1u) == g_size - 1u;
+    __syncthreads();
+    if (!s_last) return;
+    const uint64_t* src = lists;
+    uint32_t n_src = B * kp;
+    if (n_g > 1) {
+        const uint32_t n = fused_block_select(lists + (size_t) my_g * fan * kp, g_size * kp, k, keys, tid);   // (the top-k buffer is free now)
+        uint64_t* dst = lists + (size_t) (B + my_g) * kp;
+        for (uint32_t i = tid; i < kp; i += SCAN_THREADS)
+            __hip_atomic_store(dst + i, i < n ? keys[i] : KEY_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(f.done, 1u) == n_g - 1u;
+        __syncthreads();
+        if (!s_last) return;
+        src = lists + (size_t) B * kp;
+        n_src = n_g * kp;
+    }
+    const uint32_t m = fused_block_select(src, n_src, k, keys, tid);
+    {                                                       // the caller's order: one wave sorts the k keys
+        uint32_t np2 = 2;
+        while (np2 < m) np2 <<= 1;
+        for (uint32_t i = m + (uint32_t) tid; i < np2; i += SCAN_THREADS) keys[i] = KEY_EMPTY;
+        __syncthreads();
+        if (tid < 64 && m > 1) bitonic_sort_wave(keys, np2, tid);
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < k; i += SCAN_THREADS) {
+        if (i < m) {
+            const uint64_t key = keys[i];
+            const uint32_t row = (uint32_t) key;
+            const float v = mono_to_float((uint32_t) (key >> 32));
+            f.out_block[i] = f.block_ids[row];
+            f.out_doc[i] = f.doc_ids[row];
+            if (f.out_row) f.out_row[i] = f.orig_rows[row];
+            f.out_dist[i] = f.metric == M_L2 ? (float) sqrt((double) v) : v;  // vector.c:577
+            if (f.out_keys) f.out_keys[i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t) (row + f.row_offset);
+        } else {
+            f.out_block[i] = -1;
+            f.out_doc[i] = -1;
+            if (f.out_row) f.out_row[i] = -1;
+            f.out_dist[i] = __builtin_inff();
+            if (f.out_keys) f.out_keys[i] = KEY_EMPTY;
+        }
+    }
+    if (tid == 0) {
+        f.out_count[0] = (int32_t) m;
+        f.out_flag[0] = 0;
+    }
+    for (uint32_t i = tid; i < 1 + n_g; i += SCAN_THREADS) f.done[i] = 0;     // every other workgroup is past its counter
+}
+
 // C > 0: compile-time chunk count.  C == 0: runtime chunk loop (any dimension; LPR = 64, qmax <= QI).
 // QI: queries evaluated per sub-batch; up to p.qmax queries (a multiple of QI) share one pass.
 #ifndef VSR_PREFETCH
@@ -131,12 +334,13 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
     const int g = lane / LPR;
 
     // ---- which (filter, query chunk) does this workgroup serve ----
-    uint32_t lo = 0, hi = p.n_groups;
+    const bool fused = QI == 1 && p.fused.enable;                              // one query, one pass, one launch
+    uint32_t lo = 0, hi = fused ? 1u : p.n_groups;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (p.groups[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
     }
-    const ScanGroup grp = p.groups[lo];
+    const ScanGroup grp = fused ? p.fused.group : p.groups[lo];
     const auto g_tiles = as_global(grp.tiles);                                 // global_load, not flat (vsr_device.h)
     const auto g_bitmap = as_global(grp.bitmap);
     const auto g_rank = as_global(p.rank);                                     // list-ordered views: keys carry the rank
@@ -154,14 +358,14 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
     const uint32_t q_count = grp.q_count;
     const uint32_t n_sub = (q_count + QI - 1) / QI;                           // wave-uniform
     for (uint32_t qi = tid; qi < qmax; qi += SCAN_THREADS) {
-        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
+        const uint32_t slot = fused ? 0u : p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         ctrl[qi].tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         ctrl[qi].count = 0;
         qnl[qi] = (METRIC == M_COSINE) ? p.q_norm2[slot] : 0.0f;
     }
     if (tid < 4) flags[tid] = 0;
     for (uint32_t qi = 0; qi < n_sub * QI; ++qi) {                            // pad slots repeat query 0
-        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
+        const uint32_t slot = fused ? 0u : p.q_slots[grp.q_begin + (qi < q_count ? qi : 0)];
         const float4* qsrc = reinterpret_cast<const float4*>(p.queries) + (size_t) slot * stride4;
         for (uint32_t i = tid; i < stride4; i += SCAN_THREADS) qlds[(size_t) qi * stride4 + i] = qsrc[i];
     }
@@ -322,7 +526,16 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
         topk_compact<SCAN_THREADS>(keys + (size_t) qs * cap, &ctrl[qs], k, tid, false);
         const uint32_t n = ctrl[qs].count < k ? ctrl[qs].count : k;
         uint64_t* dst = p.partial + (size_t) (grp.partial_begin + qs * grp.n_blocks + local_block) * p.kp;
-        for (uint32_t i = tid; i < p.kp; i += SCAN_THREADS) dst[i] = i < n ? keys[(size_t) qs * cap + i] : KEY_EMPTY;
+        if (fused) {                                        // device-scope stores: read by another workgroup of this launch
+            for (uint32_t i = tid; i < p.kp; i += SCAN_THREADS)
+                __hip_atomic_store(dst + i, i < n ? keys[(size_t) qs * cap + i] : KEY_EMPTY, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (uint32_t i = tid; i < p.kp; i += SCAN_THREADS) dst[i] = i < n ? keys[(size_t) qs * cap + i] : KEY_EMPTY;
+        }
+    }
+    if constexpr (QI == 1) {
+        if (fused) fused_tail(p, grp, local_block, keys, tid);
     }
 }
 

@@ -48,6 +48,7 @@ SYMBOLS = {
     "vsr_search": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_search_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_search_device_on": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vsr_search_device_exact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_set_screening": (_i, [_vp, _i]),
     "vsr_screening_check": (_i, [_vp, C.POINTER(_i64), _vp, _i]),
     "vsr_merge_topk_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

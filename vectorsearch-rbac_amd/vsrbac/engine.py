@@ -310,6 +310,18 @@ class Corpus:
                                              d_doc, d_rows, d_dist, d_counts, d_keys))
         return keep
 
+    def search_device_exact(self, d_queries, nq, k, metric, filters, d_block, d_doc, d_rows, d_dist, d_counts, d_keys=None,
+                            dim=None, session=None):
+        """search_device + wait + exact re-run of whatever the screening flagged (vsr_search_device_exact): returns the
+        number of queries that were re-run; every row of the outputs is proven exact when it returns."""
+        farr, keep = self._filter_array(filters, nq)
+        n = C.c_int32(0)
+        check(self._lib.vsr_search_device_exact(session._h if session is not None else None, self._h, d_queries, nq,
+                                                self.dim if dim is None else dim, int(k), _metric(metric), farr, d_block,
+                                                d_doc, d_rows, d_dist, d_counts, d_keys, C.byref(n)))
+        del keep
+        return int(n.value)
+
 
 class IvfIndex:
     """pgvector's ivfflat scan (ivfscan.c) on the GPU: probe the nearest lists, scan them, keep the permitted top-k."""

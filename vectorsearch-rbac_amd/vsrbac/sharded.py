@@ -14,7 +14,6 @@ import ctypes
 
 import numpy as np
 
-from ._ffi import VsrError
 
 
 def shard_bounds(n_rows, world, rank, align=1):
@@ -74,6 +73,7 @@ class GpuShardEngine:
         import torch
         self.torch, self.ctx, self.corpus, self.device = torch, ctx, corpus, device
         ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self.reruns = 0                                   # flagged queries re-run so far
 
     @staticmethod
     def _p(t):
@@ -93,43 +93,11 @@ class GpuShardEngine:
                "counts": torch.empty((nq,), dtype=torch.int32, device=self.device)}
         args = (self._p(out["block"]), self._p(out["doc"]), None, self._p(out["dist"]), self._p(out["counts"]),
                 self._p(out["keys"]))
-        self._keep = self.corpus.search_device(self._p(q), nq, k, metric, filters, *args)
-        # K2 screening / seeded thresholds: queries whose exactness could not be proven are re-run on the exact path
-        _, flags = self.ctx.screening_check(nq)
-        redo = np.flatnonzero(flags)
-        if redo.size:
-            self.ctx.set_screening(False)
-            try:
-                idx = torch.from_numpy(redo).to(self.device)
-                sub = {n: torch.empty((redo.size,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
-                       for n, t in out.items()}          # (pack is attached after the fallback)
-                fl = self._subset_filters(filters, redo)
-                self._keep = self.corpus.search_device(self._p(q[idx].contiguous()), int(redo.size), k, metric, fl,
-                                                       self._p(sub["block"]), self._p(sub["doc"]), None,
-                                                       self._p(sub["dist"]), self._p(sub["counts"]), self._p(sub["keys"]))
-                # screening AND threshold seeding are off for the re-run (vsr_set_screening): it is the exact path and
-                # cannot flag again; anything else is a library fault and must not be published
-                _, again = self.ctx.screening_check(int(redo.size))
-                if again.any():
-                    raise VsrError(4, f"{int(again.sum())} queries still flagged after the exact re-run")
-                for n in out:
-                    out[n][idx] = sub[n]
-            finally:
-                self.ctx.set_screening(True)
+        # the exact variant of the device API: queries the screening could not prove exact are re-run on the exact path
+        # and patched into the record before it leaves the rank (vsr_search_device_exact)
+        self.reruns += self.corpus.search_device_exact(self._p(q), nq, k, metric, filters, *args)
         out["pack"] = pack
         return out
-
-    @staticmethod
-    def _subset_filters(filters, redo):
-        """The filters of the queries `redo`, in whatever form the caller passed them: None, one shared Filter, a list
-        of Filters, or a packed C array (Corpus.pack_filters; the handles stay owned by the original array)."""
-        if filters is None or hasattr(filters, "_h"):
-            return filters
-        if isinstance(filters, ctypes.Array):
-            sub = (ctypes.c_void_p * len(redo))(*[filters[int(i)] for i in redo])
-            sub._keep = filters
-            return sub
-        return [filters[int(i)] for i in redo]
 
     def finalize(self, local):
         return local["block"], local["doc"], local["dist"], local["counts"]
