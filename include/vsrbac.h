@@ -198,6 +198,9 @@ int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, const float* b,
 typedef struct vsr_ivf vsr_ivf;
 int vsr_ivf_load(vsr_corpus* corpus, const float* centers, int lists, const int32_t* row_list, vsr_ivf** out);
 int vsr_ivf_free(vsr_ivf* ivf);       /* before vsr_corpus_free of its corpus */
+/* index build, the pass over every row (ivfbuild.c:404-445): out_row_list[i] = nearest of `lists` centres for caller row
+ * i under the opclass distance, ties to the lower list id -- what vsr_ivf_load takes.  Host pointers; synchronises. */
+int vsr_ivf_assign(vsr_corpus* corpus, const float* centers, int lists, int metric, int32_t* out_row_list);
 int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim, int probes, int metric, int32_t* out_lists /* nq*probes */);
 int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, int probes, int metric,
                    const vsr_filter* const* filters,

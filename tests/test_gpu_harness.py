@@ -83,6 +83,53 @@ def test_search_functions_match_oracle(ctx, oracle, world):
     dep.close()
 
 
+def test_placed_partitions_equal_single_corpus(ctx, oracle, world):
+    """whole partitions placed on GPUs by LPT (hot ones replicated); a query touches only the
+    GPUs holding its combination's partitions and the merged rows equal the one-corpus dynamic-partition search and
+    the oracle.  Three contexts of the one GPU stand in for three GPUs."""
+    import vsrbac
+    from vsrbac.harness import Deployment, parse_vector
+    from vsrbac.placement import PlacedDeployment
+    fx, x, blk, doc = world
+    ndocs = fx["params"]["num_docs"]
+    # overlapping partitions (impure + shared documents): partition p holds documents with d % 5 in {p, p + 1}
+    part_docs = {p: [d for d in range(1, ndocs + 1) if d % 5 in (p, (p + 1) % 5)] for p in range(5)}
+    role_docs = {}
+    for r, d in fx["permissions"]:
+        role_docs.setdefault(r, set()).add(d)
+    combs = {}
+    for u in range(1, fx["num_users"] + 1):
+        roles = tuple(sorted(r for uu, r in fx["user_roles"] if uu == u))
+        vis = set().union(*[role_docs.get(r, set()) for r in roles]) if roles else set()
+        need, covered = [], set()
+        for p, ds in part_docs.items():                      # a cover of the visible documents, like the planner's
+            gain = (vis & set(ds)) - covered
+            if gain:
+                need.append(p)
+                covered |= gain
+        combs[roles] = need
+    weights = {c: 1.0 + 9.0 * (i == 0) for i, c in enumerate(sorted(combs))}     # one hot combination
+    ctxs = [ctx, vsrbac.Context(0), vsrbac.Context(0)]
+    placed = PlacedDeployment(ctxs, x, blk, doc, fx["user_roles"], fx["permissions"], part_docs, combs, weights)
+    assert set(placed.placement) == set(part_docs) and all(gs for gs in placed.placement.values())
+    assert max(len(gs) for gs in placed.placement.values()) > 1, "the hot partitions should have been replicated"
+    single = Deployment(ctx, x, blk, doc, fx["user_roles"], fx["permissions"])
+    single.load_partitions(part_docs, combs)
+    rng = np.random.default_rng(5)
+    for u, r in zip(rng.integers(1, fx["num_users"] + 1, 10), rng.integers(0, len(x), 10)):
+        qv = _vec_text(x[r])
+        got, _ = placed.dynamic_partition_search(int(u), qv, 10)
+        want, _ = single.dynamic_partition_search(int(u), qv, 10)
+        assert [(g[0], g[1], np.float32(g[3])) for g in got] == [(w[0], w[1], np.float32(w[3])) for w in want]
+        mask = oracle.user_row_mask(int(u), fx["user_roles"], fx["permissions"], doc)
+        idx, d = oracle.filtered_topk("l2", x, parse_vector(qv), 10, doc, blk, mask)
+        assert [(g[0], g[1]) for g in got] == [(int(blk[i]), int(doc[i])) for i in idx]
+    single.close()
+    placed.close()
+    for c in ctxs[1:]:
+        c.close()
+
+
 @pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("parts", [2, 3, 8])
 def test_sharded_merge_equals_single_gpu(ctx, oracle, world, parts, shared):

@@ -73,6 +73,27 @@ def test_ivf_probe_and_search_match_the_oracle(ctx, oracle, sift60k, nq):
     corpus.free()
 
 
+def test_ivf_build_assignment_on_the_gpu(ctx, oracle, sift60k):
+    """Index build, the pass over every row (ivfbuild.c:404-445): the GPU assigns all rows to their nearest centre
+    exactly as the index oracle does (same arithmetic, ties to the lower list), in the caller's row order even when the
+    corpus is stored in another order; an index loaded from that assignment answers like one loaded from the oracle's."""
+    x, blk, doc, oivf = sift60k
+    rng = np.random.default_rng(91)
+    perm = rng.permutation(len(x))                       # caller order != (document, block) order
+    corpus = ctx.load_corpus(x[perm], blk[perm], doc[perm])
+    got = corpus.ivf_assign(oivf.centers, "l2")
+    np.testing.assert_array_equal(got, oivf.assign[perm])
+    gpu = corpus.load_ivf(oivf.centers, got)
+    q = x[rng.integers(0, len(x), 8)]
+    res = gpu.search(q, 20, 3, "l2")
+    for i in range(8):
+        idx, dist = oivf.search(q[i], 20, 3)
+        np.testing.assert_array_equal(res.block_ids[i], blk[idx])
+        np.testing.assert_array_equal(res.dist[i], dist.astype(np.float32))
+    gpu.free()
+    corpus.free()
+
+
 def test_ivf_cosine_opclass_on_unit_rows(ctx, oracle):
     """vector_cosine_ops: spherical k-means centres, probe by negative inner product, rows are unit vectors."""
     rng = np.random.default_rng(71)

@@ -123,3 +123,33 @@ def test_planner_output_to_tables():
     import pytest
     with pytest.raises(ValueError, match="unknown partitions"):
         planner_output_to_tables(pa, {(1,): {42: {1}}})
+
+
+def test_gpu_cost_model_and_placement():
+    """f3: the planner's objective with the GPU's cost of a partition search (same argument list as the reference's
+    compute_query_time, AnonySys_dynamic_partition.py:114) and LPT placement of partitions on GPUs."""
+    from vsrbac.placement import compute_query_time_gpu, partition_heat, place_partitions
+    comb_trackers = {(1,): {0, 1}, (2,): {1, 2}, (1, 2): {0, 1, 2, 3}}
+    loads = {0: 1000, 1: 50000, 2: 2000, 3: 300}
+    w = {(1,): 5.0, (2,): 1.0, (1, 2): 0.5}
+    # the reference's positional call shape (sel_whole, topk, k, beta, a, b are HNSW tuning values: ignored here)
+    t_all = compute_query_time_gpu(comb_trackers, loads, 0.1, 10, 0.5, 0.2, 1.0, 0.0, set(comb_trackers), w)
+    t_one = compute_query_time_gpu(comb_trackers, loads, 0.1, 10, 0.5, 0.2, 1.0, 0.0, {(1,)}, w)
+    assert 0 < t_one < t_all
+    # moving the big partition out of a heavy combination's cover must lower the objective
+    lighter = dict(comb_trackers)
+    lighter[(1,)] = {0}
+    assert compute_query_time_gpu(lighter, loads, comb_to_update=set(lighter), role_weights=w) < \
+        compute_query_time_gpu(comb_trackers, loads, comb_to_update=set(comb_trackers), role_weights=w)
+    heat = partition_heat(comb_trackers, loads, w)
+    assert max(heat, key=heat.get) == 1
+    placement, gpu_heat, gpu_rows = place_partitions(loads, heat, 4)
+    assert set(placement) == set(loads) and all(len(set(g)) == len(g) >= 1 for g in placement.values())
+    assert len(placement[1]) > 1, "the partition that dominates the load is replicated"
+    assert sum(gpu_rows) == sum(loads[p] * len(g) for p, g in placement.items())
+    assert max(gpu_heat) <= 0.75 * sum(heat.values()), gpu_heat       # no GPU carries (nearly) everything
+    one, h1, _ = place_partitions(loads, heat, 1)
+    assert all(g == [0] for g in one.values()) and abs(h1[0] - sum(heat.values())) < 1e-6
+    import pytest
+    with pytest.raises(ValueError):
+        place_partitions(loads, heat, 2, mem_rows=10000)

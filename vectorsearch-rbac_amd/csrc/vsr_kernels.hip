@@ -1052,14 +1052,14 @@ hipError_t launch_view_bitmap(const uint32_t* rank, uint32_t n_rows, const uint2
 // GetScanLists (ivfscan.c:36-107): per query the `probes` nearest of `lists` centres under the opclass distance (L2
 // squared, or negative inner product), nearest first, the lower list id first among equals.  One workgroup per query.
 // The sums run in the order and rounding of vector.c's loops compiled without contraction (one lane per centre).
-__global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, const float* centers, int dim, int lists, int probes,
-                                                        int metric, int32_t* out)
+__global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, uint32_t q_stride, const float* centers, int dim,
+                                                        int lists, int probes, int metric, int32_t* out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);     // [lists]
     __shared__ uint64_t s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* q = queries + (size_t) blockIdx.x * dim;
+    const float* q = queries + (size_t) blockIdx.x * q_stride;         // (corpus rows as queries: the index build's assignment)
     for (int c = tid; c < lists; c += 256) {
         const float* x = centers + (size_t) c * dim;
         float sum = 0.0f;
@@ -1095,13 +1095,13 @@ __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, co
     }
 }
 
-hipError_t launch_ivf_probe(const float* queries, uint32_t nq, const float* centers, int dim, int lists, int probes, int metric,
-                            int32_t* out, hipStream_t s)
+hipError_t launch_ivf_probe(const float* queries, uint32_t q_stride, uint32_t nq, const float* centers, int dim, int lists, int probes,
+                            int metric, int32_t* out, hipStream_t s)
 {
     if (nq == 0) return hipSuccess;
     const size_t lds = (size_t) lists * sizeof(uint64_t);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ivf_probe_kernel, dim3(nq), dim3(256), lds, s, queries, centers, dim, lists, probes, metric, out);
+    hipLaunchKernelGGL(ivf_probe_kernel, dim3(nq), dim3(256), lds, s, queries, q_stride, centers, dim, lists, probes, metric, out);
     return hipGetLastError();
 }
 

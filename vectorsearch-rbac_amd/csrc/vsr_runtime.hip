@@ -2539,7 +2539,7 @@ extern "C" int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int di
     if ((rc = ivf->d_q.reserve((size_t) nq * dim * sizeof(float)))) return rc;
     if ((rc = ivf->d_probe.reserve((size_t) nq * probes * sizeof(int32_t)))) return rc;
     HIPCHK(hipMemcpyAsync(ivf->d_q.p, queries, (size_t) nq * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(launch_ivf_probe(ivf->d_q.as<float>(), (uint32_t) nq, ivf->d_centers, dim, ivf->lists, probes,
+    HIPCHK(launch_ivf_probe(ivf->d_q.as<float>(), (uint32_t) dim, (uint32_t) nq, ivf->d_centers, dim, ivf->lists, probes,
                             metric == VSR_METRIC_L2 ? M_L2 : M_IP, ivf->d_probe.as<int32_t>(), ctx->stream));
     std::vector<int32_t> probe((size_t) nq * probes);
     HIPCHK(hipMemcpyAsync(probe.data(), ivf->d_probe.p, probe.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2581,10 +2581,41 @@ extern "C" int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim
     if ((rc = ivf->d_q.reserve((size_t) nq * dim * sizeof(float)))) return rc;
     if ((rc = ivf->d_probe.reserve((size_t) nq * probes * sizeof(int32_t)))) return rc;
     HIPCHK(hipMemcpyAsync(ivf->d_q.p, queries, (size_t) nq * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(launch_ivf_probe(ivf->d_q.as<float>(), (uint32_t) nq, ivf->d_centers, dim, ivf->lists, probes,
+    HIPCHK(launch_ivf_probe(ivf->d_q.as<float>(), (uint32_t) dim, (uint32_t) nq, ivf->d_centers, dim, ivf->lists, probes,
                             metric == VSR_METRIC_L2 ? M_L2 : M_IP, ivf->d_probe.as<int32_t>(), ctx->stream));
     HIPCHK(hipMemcpyAsync(out_lists, ivf->d_probe.p, (size_t) nq * probes * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return VSR_OK;
+}
+
+// Index build, the part that touches every row (ivfbuild.c:404-445: InsertTuples finds the nearest list of each heap
+// row): all corpus rows against the centres, in the index's arithmetic, on the GPU.  The k-means that produces the
+// centres from a small sample (ivfkmeans.c) is not on the GPU; see DESIGN.md section 7.
+extern "C" int vsr_ivf_assign(vsr_corpus* c, const float* centers, int lists, int metric, int32_t* out_row_list)
+{
+    if (!c || !centers || (c->n > 0 && !out_row_list)) return fail(VSR_ERR_INVALID, "vsr_ivf_assign: NULL argument");
+    if (c->base) return fail(VSR_ERR_INVALID, "vsr_ivf_assign: the corpus is a view");
+    if (lists < 1 || lists > 8192) return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_assign: lists must be between 1 and 8192 (got %d)", lists);
+    if (metric != VSR_METRIC_L2 && metric != VSR_METRIC_IP && metric != VSR_METRIC_COSINE)
+        return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_assign: metric %d has no ivfflat opclass", metric);
+    vsr_ctx* ctx = c->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = c->n;
+    if (n == 0) return VSR_OK;
+    DevBuf d_centers, d_out;
+    struct Guard { DevBuf &a, &b; ~Guard() { a.release(); b.release(); } } guard{d_centers, d_out};
+    int rc;
+    if ((rc = d_centers.reserve((size_t) lists * c->dim * sizeof(float)))) return rc;
+    if ((rc = d_out.reserve((size_t) n * sizeof(int32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(d_centers.p, centers, (size_t) lists * c->dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // cosine opclass: rows and centres are compared by the negative inner product (spherical k-means, vector.sql:323-327)
+    HIPCHK(launch_ivf_probe(reinterpret_cast<const float*>(c->d_rows), (uint32_t) c->stride4 * 4, (uint32_t) n,
+                            d_centers.as<float>(), c->dim, lists, 1, metric == VSR_METRIC_L2 ? M_L2 : M_IP, d_out.as<int32_t>(),
+                            ctx->stream));
+    std::vector<int32_t> by_internal((size_t) n);
+    HIPCHK(hipMemcpyAsync(by_internal.data(), d_out.p, (size_t) n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int64_t r = 0; r < n; ++r) out_row_list[c->h_orig[(size_t) r]] = by_internal[(size_t) r];     // caller's row order
     return VSR_OK;
 }
 

@@ -310,6 +310,16 @@ class Corpus:
                                              d_doc, d_rows, d_dist, d_counts, d_keys))
         return keep
 
+    def ivf_assign(self, centers, metric="l2"):
+        """The pass of the ivfflat build that touches every row (ivfbuild.c:404-445): the nearest centre of each row, in
+        the caller's row order -- the `row_list` IvfIndex / vsr_ivf_load take."""
+        c = np.ascontiguousarray(centers, dtype=np.float32)
+        if c.ndim != 2 or c.shape[1] != self.dim:
+            raise VsrError(_ffi.ERR_INVALID, f"centers must be (lists, {self.dim})")
+        out = np.zeros(self.n, dtype=np.int32)
+        check(self._lib.vsr_ivf_assign(self._h, _ptr(c), int(c.shape[0]), _metric(metric), _ptr(out)))
+        return out
+
     def search_device_exact(self, d_queries, nq, k, metric, filters, d_block, d_doc, d_rows, d_dist, d_counts, d_keys=None,
                             dim=None, session=None):
         """search_device + wait + exact re-run of whatever the screening flagged (vsr_search_device_exact): returns the
