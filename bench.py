@@ -87,11 +87,15 @@ def self_launch(args):
 
 
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md); the fp32 MFMA peak is MFMA_F32_PEAK_TF
+MFMA_I8_PEAK_TOPS = 5000.0      # dense int8 MFMA peak, same guide (ops, reported in the TFLOP/s fields)
 
 
 def kernel_layout(kernel, dim):
     """(bytes per row the launch reads, MFMA flops per (row, query) pair it issues, MFMA peak) for the launched kernel."""
     if "K2w" in kernel:
+        if "PL=int8" in kernel:          # int8 planes (x - 128), 128 elements per row; one product, exact
+            d_pad = -(-dim // 128) * 128
+            return d_pad + 4, 2 * d_pad, MFMA_I8_PEAK_TOPS
         if "HO=true" in kernel:          # hi-only bf16 planes, rows padded to whole 128-element stages; products xh*qh + xh*qm
             d_pad = -(-dim // 128) * 128
             return d_pad * 2 + 4, 2 * 2 * d_pad, MFMA_BF16_PEAK_TF
@@ -235,6 +239,11 @@ def main():
         cx = vsrbac.Context(local_rank)
         cx.set_stream(sx.cuda_stream)
         sessions.append(cx)
+    # SIFT queries are uint8 like the corpus (the query vectors are corpus rows, read_dataset_function.py:736-737): the
+    # library is told so and verifies it per query on the device (vsr_set_query_hint; a violation would flag and abort)
+    if os.environ.get("VSR_BENCH_NO_U8_HINT") != "1":
+        for sx in sessions:
+            sx.set_query_hint(True)
         s_scan.append(sx)
     if parts > 1:
         g_packs = [torch.full((parts * rec,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(nbuf)]   # [parts] records

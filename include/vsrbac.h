@@ -163,6 +163,12 @@ int vsr_search_device_exact(vsr_ctx* session, vsr_corpus* corpus, const float* d
  * flagged queries themselves.  After the asynchronous vsr_search_device(_on) the caller either tests the counts on the
  * device or calls vsr_screening_check: flagged_total = flagged queries since vsr_open, flags_last_call[i] != 0 =
  * query i of the last call must be re-run with screening disabled.  vsr_screening_check synchronises. */
+/* Queries of a SIFT-like workload: a corpus whose elements are all integers 0..255 (d <= 128) also keeps int8 planes, and
+ * L2 searches whose QUERIES are such integers too screen on them (a quarter of the fp32 bytes per row).  Host queries
+ * (vsr_search) are checked by the library.  For device-resident queries the caller states it: u8_queries != 0 promises
+ * that the queries of this context's vsr_search_device calls are integer-valued in 0..255.  The promise is verified on
+ * the device: a query that breaks it is FLAGGED (re-run like any flagged query) and the hint is dropped. */
+int vsr_set_query_hint(vsr_ctx* ctx, int u8_queries);
 int vsr_set_screening(vsr_ctx* ctx, int enable);           /* default: enabled; 0 also disables threshold seeding, so
                                                               searches of that context are exact and never flag */
 int vsr_screening_check(vsr_ctx* ctx, int64_t* flagged_total, int32_t* flags_last_call, int nq);

@@ -649,6 +649,68 @@ def test_wide_shared_passes_exact(ctx, oracle, dim, nq):
     corpus.free()
 
 
+def test_int8_planes_for_sift_like_queries(ctx, oracle):
+    """A corpus of integers 0..255 (d <= 128) keeps int8 planes; L2 searches whose queries are such integers screen on
+    them (v_mfma_i32_16x16x64_i8, exact).  Host queries are checked by the library; device-resident queries only under
+    vsr_set_query_hint, verified per query on the device: a query that breaks the promise is flagged (negative count),
+    the exact variant re-runs it, and the hint is dropped."""
+    import torch
+    import vsrbac
+    rng = np.random.default_rng(4242)
+    n, dim, k, nq = 80_000, 128, 100, 96
+    x = sift_like(rng, n)
+    blk, doc = _ids(n, 40)
+    corpus = ctx.load_corpus(x, blk, doc)
+    q = x[rng.integers(0, n, nq)].copy()
+    q[:, :7] = rng.integers(0, 256, (nq, 7)).astype(np.float32)        # still integers 0..255, no longer corpus rows
+    res = corpus.search(q, k, "l2")
+    assert "PL=int8" in ctx.last_scan_kernel(), ctx.last_scan_kernel()
+    for i in range(0, nq, 7):
+        _expect_exact(oracle, res, i, "l2", x, q[i], k, doc, blk)
+    q2 = q.copy()
+    q2[5, 3] = 17.5                                                    # one non-integer element: bf16 planes for this call
+    res = corpus.search(q2, k, "l2")
+    assert "PL=int8" not in ctx.last_scan_kernel()
+    _expect_exact(oracle, res, 5, "l2", x, q2[5], k, doc, blk)
+    res = corpus.search(q, k, "ip")                                    # int8 planes are an L2 path only
+    assert "PL=int8" not in ctx.last_scan_kernel()
+    # device-resident queries: nothing is assumed without the hint
+    dev = torch.device("cuda", 0)
+    outs = (torch.empty((nq, k), dtype=torch.int64, device=dev), torch.empty((nq, k), dtype=torch.int32, device=dev),
+            torch.empty((nq, k), dtype=torch.int64, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+            torch.empty((nq,), dtype=torch.int32, device=dev))
+    ptrs = tuple(t.data_ptr() for t in outs)
+    d_q = torch.from_numpy(q).to(dev)
+    corpus.search_device(d_q.data_ptr(), nq, k, "l2", None, *ptrs)
+    ctx.synchronize()
+    assert "PL=int8" not in ctx.last_scan_kernel()
+    ctx.set_query_hint(True)
+    corpus.search_device(d_q.data_ptr(), nq, k, "l2", None, *ptrs)
+    _, flags = ctx.screening_check(nq)
+    assert "PL=int8" in ctx.last_scan_kernel() and not flags.any()
+    got = SimpleNamespace(block_ids=outs[0].cpu().numpy(), doc_ids=outs[1].cpu().numpy(), rows=outs[2].cpu().numpy(),
+                          dist=outs[3].cpu().numpy(), counts=outs[4].cpu().numpy())
+    for i in range(0, nq, 9):
+        _expect_exact(oracle, got, i, "l2", x, q[i], k, doc, blk)
+    d_q2 = torch.from_numpy(q2).to(dev)                                # the promise is broken by query 5
+    corpus.search_device(d_q2.data_ptr(), nq, k, "l2", None, *ptrs)
+    _, flags = ctx.screening_check(nq)
+    cnt = outs[4].cpu().numpy()
+    assert flags[5] and cnt[5] < 0 and int(flags.sum()) == 1
+    ctx.set_query_hint(True)
+    n_rerun = corpus.search_device_exact(d_q2.data_ptr(), nq, k, "l2", None, *ptrs)
+    assert n_rerun == 1
+    got = SimpleNamespace(block_ids=outs[0].cpu().numpy(), doc_ids=outs[1].cpu().numpy(), rows=outs[2].cpu().numpy(),
+                          dist=outs[3].cpu().numpy(), counts=outs[4].cpu().numpy())
+    for i in (4, 5, 6):
+        _expect_exact(oracle, got, i, "l2", x, q2[i], k, doc, blk)
+    corpus.search_device(d_q.data_ptr(), nq, k, "l2", None, *ptrs)     # the violation dropped the hint
+    ctx.synchronize()
+    assert "PL=int8" not in ctx.last_scan_kernel()
+    ctx.set_query_hint(False)
+    corpus.free()
+
+
 def vsrbac_mode(rng):
     import vsrbac
     return vsrbac.RANGES if rng.random() < 0.5 else vsrbac.BITMAP

@@ -7,6 +7,7 @@ namespace vsr {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;   // native vector: loads as one dwordx4 and stays in registers
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using i32x4 = __attribute__((ext_vector_type(4))) int;       // A / B fragment and accumulator of v_mfma_i32_16x16x64_i8
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16; // A / B fragment of v_mfma_f32_16x16x32_bf16
 
 // Explicit address spaces.  A pointer that comes out of a struct in memory (ScanGroup::tiles / bitmap) or an access the
@@ -103,7 +104,8 @@ struct ScanParams {
     const uint4*     scr;          // [n_rows][pstride4] 16-byte chunks
     const uint4*     q_scr;        // [n_slots][pstride4]
     uint32_t         pstride4;     // 16-byte chunks per corpus plane row (plane_stride4)
-    uint32_t         plane_ho;     // 1: hi-only corpus planes (every element exactly a bf16 value), 128 floats per stage
+    uint32_t         plane_ho;     // plane kind: 0 bf16 hi + mid; 1 bf16 hi only (every element exactly a bf16 value), 128
+                                   // floats per stage; 2 int8 (u8-exact corpus and queries, x - 128; L2; 128 bytes per row)
     // K2w candidates: one buffer of capq keys per query slot, filled with returning atomics on qcnt (may exceed capq)
     uint64_t*        qcand;        // [n_slots][capq]
     uint32_t*        qcnt;         // [n_slots]
@@ -181,6 +183,7 @@ struct RerankParams {
     const uint32_t*    qcnt;           // [n_slots] appended keys (may exceed capq: overflow)
     uint32_t           capq;
     float              err_g;          // relative error bound of the screening dot product: |dot_s - dot| <= err_g |x| |q|
+    const uint32_t*    qbad;           // [n_slots] != 0: the query's screening input was invalid (int8 path): flag it
     int                seeded;         // thresholds were seeded from a sample: also check completeness
     const uint64_t*    tau_init;       // [n_slots] the seeds (bound on every excluded row when the list is not full)
     int32_t*           out_flags;      // [n_queries] by out_slot: 1 = screening gap inside the error bound
@@ -284,8 +287,16 @@ struct StageParams {
     uint64_t*    tau;              // [nq] <- KEY_EMPTY (no seed)
     uint32_t*    qcnt;             // [nq] <- 0: K2w candidate counts (nullptr: not used)
     uint32_t*    scnt;             // [nq] <- 0: K2w sample counts
+    uint4*       q_scr8;           // [nq][8] int8 planes of the queries (q - 128, 16 per chunk), nullptr: not needed
+    float*       q_norm2_8;        // [nq] sum (q - 128)^2 over the padded row
+    uint32_t*    q8_bad;           // [nq] <- 1 for a query that is not integer-valued in 0..255 (select_rerank flags it)
+    uint32_t*    q8_bad_host;      // pinned host word <- 1 if any such query (the session then leaves the int8 path)
 };
 hipError_t launch_stage(const StageParams& p, hipStream_t s);
+// int8 planes of a u8-exact corpus (d <= 128): scr8[row][8 chunks of 16 elements x - 128, zero padded], norm8 = sum (x-128)^2
+hipError_t launch_check_u8_exact(const float4* rows, uint32_t n_rows, uint32_t stride4, uint32_t* any_inexact, hipStream_t s);
+hipError_t launch_split_planes8(const float4* rows, uint32_t n_rows, uint32_t stride4, uint32_t dim, uint4* scr8, float* norm8,
+                                hipStream_t s);
 hipError_t launch_row_norms(const float4* rows, uint32_t n_rows, uint32_t stride4, float* norm2, hipStream_t s);
 hipError_t launch_build_bitmap(const uint32_t* row_doc_idx, uint32_t n_rows, const uint64_t* doc_mask,
                                uint32_t words, const uint64_t* user_mask, uint64_t* bitmap, hipStream_t s);

@@ -551,6 +551,83 @@ hipError_t launch_check_bf16_exact(const float4* rows, uint32_t n_rows, uint32_t
     return hipGetLastError();
 }
 
+// is every element an integer in 0..255?
+__global__ __launch_bounds__(256) void check_u8_exact_kernel(const float4* rows, uint64_t n4, uint32_t* any_inexact)
+{
+    bool bad = false;
+    auto ok = [](float v) { return v >= 0.0f && v <= 255.0f && v == floorf(v); };
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t) gridDim.x * 256) {
+        const float4 v = rows[i];
+        bad |= !(ok(v.x) && ok(v.y) && ok(v.z) && ok(v.w));
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(any_inexact, 1u);
+}
+
+hipError_t launch_check_u8_exact(const float4* rows, uint32_t n_rows, uint32_t stride4, uint32_t* any_inexact, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t n4 = (uint64_t) n_rows * stride4;
+    uint32_t blocks = (uint32_t) std::min<uint64_t>((n4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(check_u8_exact_kernel, dim3(blocks), dim3(256), 0, s, rows, n4, any_inexact);
+    return hipGetLastError();
+}
+
+// 16 consecutive elements of a padded fp32 row -> one chunk of int8 (x - 128; elements past dim: 0); returns sum (x-128)^2
+__device__ __forceinline__ float chunk8(const float4* row, uint32_t stride4, uint32_t dim, uint32_t c, uint4& out, bool& bad)
+{
+    uint32_t w[4];
+    float n2 = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const uint32_t f4 = c * 4 + (uint32_t) f;
+        const float4 v = f4 < stride4 ? row[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t j = f4 * 4 + (uint32_t) e;
+            int b = 0;
+            if (j < dim) {
+                bad |= !(x[e] >= 0.0f && x[e] <= 255.0f && x[e] == floorf(x[e]));
+                const float cl = fminf(fmaxf(x[e], 0.0f), 255.0f);
+                b = (int) cl - 128;
+                n2 += (float) (b * b);                      // integers below 2^24: exact in any order
+            }
+            word |= ((uint32_t) b & 0xFFu) << (8 * e);
+        }
+        w[f] = word;
+    }
+    out = make_uint4(w[0], w[1], w[2], w[3]);
+    return n2;
+}
+
+__global__ __launch_bounds__(256) void split_planes8_kernel(const float4* rows, uint32_t n_rows, uint32_t stride4, uint32_t dim,
+                                                            uint4* scr8, float* norm8)
+{
+    // 8 threads per row, one chunk each; the row's norm by a shuffle over the 8
+    const uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = (uint32_t) (i >> 3), c = (uint32_t) (i & 7);
+    const bool live = r < n_rows;
+    uint4 out = make_uint4(0u, 0u, 0u, 0u);
+    bool bad = false;
+    float n2 = live ? chunk8(rows + (size_t) r * stride4, stride4, dim, c, out, bad) : 0.0f;
+    if (live) scr8[(size_t) r * 8 + c] = out;
+    n2 += __shfl_xor(n2, 1);
+    n2 += __shfl_xor(n2, 2);
+    n2 += __shfl_xor(n2, 4);
+    if (live && c == 0) norm8[r] = n2;
+}
+
+hipError_t launch_split_planes8(const float4* rows, uint32_t n_rows, uint32_t stride4, uint32_t dim, uint4* scr8, float* norm8,
+                                hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t) n_rows * 8;
+    hipLaunchKernelGGL(split_planes8_kernel, dim3((uint32_t) ((threads + 255) / 256)), dim3(256), 0, s, rows, n_rows, stride4, dim,
+                       scr8, norm8);
+    return hipGetLastError();
+}
+
 // Per-batch staging, see StageParams.  Workgroups [0, nq): one query each; the rest copy the descriptor block.
 __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
 {
@@ -577,6 +654,22 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
         for (uint32_t item = (uint32_t) tid; item < items; item += 256)
             split_row_item(reinterpret_cast<const float4*>(dst), p.qfloats / 4, p.q_scr + (size_t) s * qstride, item,
                            p.plane_ho != 0, 32u, 16u);
+    }
+    if (p.q_scr8 && tid >= 64 && tid < 72) {                 // int8 path: the query as q - 128, validated
+        const uint32_t c = (uint32_t) tid - 64;
+        uint4 out;
+        bool bad = false;
+        float n2 = chunk8(reinterpret_cast<const float4*>(dst), p.qfloats / 4, p.dim, c, out, bad);
+        p.q_scr8[(size_t) s * 8 + c] = out;
+        n2 += __shfl_xor(n2, 1);
+        n2 += __shfl_xor(n2, 2);
+        n2 += __shfl_xor(n2, 4);
+        const bool any_bad = __ballot(bad) != 0;
+        if (c == 0) {
+            p.q_norm2_8[s] = n2;
+            p.q8_bad[s] = any_bad ? 1u : 0u;
+            if (any_bad) *p.q8_bad_host = 1u;
+        }
     }
     if (tid < 64) {                                          // the arithmetic of row_norms_kernel, one wave per row
         const float4* row = reinterpret_cast<const float4*>(dst);
@@ -952,7 +1045,7 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(const RerankParams p
         if (lane == 0) s_worst = n >= p.kp ? kth : KEY_EMPTY;
     }
     __syncthreads();
-    rerank_body(p, slot, keys, np2, s_worst, cnt > p.capq);
+    rerank_body(p, slot, keys, np2, s_worst, cnt > p.capq || (p.qbad && p.qbad[slot]));
 }
 
 hipError_t launch_select_rerank(const RerankParams& p, uint32_t n_queries, hipStream_t s)

@@ -80,9 +80,16 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // NCH: stages per row (16 chunks = 256 bytes each): 64 floats per stage with hi + mid planes, 128 floats hi-only.
-template <int METRIC, int NCH, bool SAMPLE, bool HO, int DEPTH>
+// PL: plane kind of the corpus (ScanParams::plane_ho): 0 = bf16 hi + mid, 1 = bf16 hi only, 2 = int8 (u8-exact corpus and
+// queries, elements stored as x - 128; L2 only: |x' - q'|^2 = |x - q|^2, exact in int32 / fp32; 128 bytes per row, the
+// tile image has 8 chunks per row and v_mfma_i32_16x16x64_i8 covers d = 128 in two instructions).
+template <int METRIC, int NCH, bool SAMPLE, int PL, int DEPTH>
 __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(const ScanParams p)
 {
+    constexpr bool HO = PL == 1, I8 = PL == 2;
+    constexpr int SR = I8 ? 8 : MW_S;                                          // 16-byte chunks per row and stage
+    constexpr int NU = I8 ? 2 : 4;                                             // chunks a thread stages per tile and stage
+    static_assert(!I8 || (NCH == 1 && METRIC == M_L2), "int8 planes: one stage (d <= 128), L2 only");
     static_assert(DEPTH >= 1 && DEPTH <= 4 && DEPTH + 2 <= MW_RING, "row-mapping ring too short");
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -135,8 +142,9 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     const int li = lane & 15;
     const int kq = lane >> 4;
     const int jq = li;
-    constexpr int NBLK = HO ? 4 : 2;                                           // K-blocks of 32 per stage
+    constexpr int NBLK = I8 ? 2 : HO ? 4 : 2;                                  // K-blocks per stage (32 bf16 or 64 int8 each)
     bf16x8 bh[NCH][NBLK], bm[NCH][NBLK];                                        // B fragments: hi / mid planes of the query
+    i32x4 b8[NBLK];                                                            // ... or its int8 plane
     const uint32_t my_qi = g0 * MF_NQ + (uint32_t) jq < (uint32_t) MW_NQ ? g0 * MF_NQ + (uint32_t) jq : 0u;
     float my_qn;
     uint32_t my_slot;
@@ -148,13 +156,18 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
         my_qn = p.q_norm2[slot];
         // query planes: per stage [hi chunks | mid chunks] (8 + 8 of a 64-float stage; 16 + 16 of a 128-float one)
         const uint4* qsrc = p.q_scr + (size_t) slot * (HO ? 2 * pstride4 : pstride4);
+        if constexpr (I8) {
 #pragma unroll
-        for (int s = 0; s < NCH; ++s)
+            for (int blk = 0; blk < NBLK; ++blk) b8[blk] = __builtin_bit_cast(i32x4, qsrc[blk * 4 + kq]);
+        } else {
 #pragma unroll
-            for (int blk = 0; blk < NBLK; ++blk) {
-                bh[s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * (HO ? 32 : 16) + blk * 4 + kq]);
-                bm[s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * (HO ? 32 : 16) + (HO ? 16 : 8) + blk * 4 + kq]);
-            }
+            for (int s = 0; s < NCH; ++s)
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    bh[s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * (HO ? 32 : 16) + blk * 4 + kq]);
+                    bm[s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * (HO ? 32 : 16) + (HO ? 16 : 8) + blk * 4 + kq]);
+                }
+        }
     }
 
     // ---- this workgroup's tiles ----
@@ -238,8 +251,9 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
     __syncthreads();
 
     // ---- staging: thread -> (row slot u * 16 + lrow, chunk lchunk) of every stage ----
-    const int lrow = tid >> 4, lchunk = tid & 15;
-    uint4 X[DEPTH][NCH][4];
+    const int lrow = I8 ? tid >> 3 : tid >> 4, lchunk = I8 ? tid & 7 : tid & 15;
+    constexpr int LROWS = I8 ? 32 : 16;                            // row slots one staging step of the workgroup covers
+    uint4 X[DEPTH][NCH][NU];
     const uint32_t last_row = p.n_rows - 1u;
     auto issue = [&](auto dc, auto sc, uint32_t it_) {             // loads of tile it_, stage S into ring slot D (no waits)
         // An invalid slot (masked row, ragged tile) loads row 0 and its products are discarded by the epilogue's row
@@ -247,11 +261,11 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
         // padded to whole stages, so every chunk index is in range.
         constexpr int D = decltype(dc)::value;
         constexpr int S = decltype(sc)::value;
-        const uint32_t chunk = (uint32_t) (S * MW_S + lchunk);
+        const uint32_t chunk = (uint32_t) (S * SR + lchunk);
         const int32_t* ridx = rowidx + (it_ % MW_RING) * 64;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int32_t r = ridx[u * 16 + lrow];
+        for (int u = 0; u < NU; ++u) {
+            const int32_t r = ridx[u * LROWS + lrow];
             const uint32_t rc = (uint32_t) (r < 0 ? 0 : r);
             if ((VSR_ABLATE & 8) && it_ > 0) continue;
             const u32x4 v = *reinterpret_cast<const u32x4*>(p.scr + (size_t) (rc < last_row ? rc : last_row) * pstride4 + chunk);
@@ -353,16 +367,20 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
         auto tile = [&](auto dc, uint32_t it) {
             constexpr int D = decltype(dc)::value;
             f32x4 acc[NS];
+            i32x4 acc8[NS];                                        // int8 planes: exact integer dot products
 #pragma unroll
-            for (int i = 0; i < NS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NS; ++i) {
+                acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc8[i] = i32x4{0, 0, 0, 0};
+            }
 
             auto do_stage = [&](auto sc) {
                 constexpr int S = decltype(sc)::value;
                 uint4* img = stage + (size_t) buf * (MW_ROWS * MW_S);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int slot = u * 16 + lrow;
-                    img[slot * MW_S + (lchunk ^ (slot & 15))] = X[D][S][u];      // XOR-swizzled image
+                for (int u = 0; u < NU; ++u) {
+                    const int slot = u * LROWS + lrow;
+                    img[slot * SR + (lchunk ^ (slot & (SR - 1)))] = X[D][S][u];  // XOR-swizzled image
                 }
                 if constexpr (S == 0) {                            // row mapping, one step per tile (see above)
                     if (f_n) flush_store();                        // the image write above waited for this tile's rows, which
@@ -377,7 +395,21 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
                 }
                 issue(dc, sc, it + DEPTH);                         // in flight under the work of DEPTH whole tiles (past the
                                                                    // last tile: all slots invalid, row 0 from the cache)
-                if (gact && !(VSR_ABLATE & 4)) {
+                if constexpr (I8) {
+                    if (gact && !(VSR_ABLATE & 4)) {
+#pragma unroll
+                        for (int blk = 0; blk < NBLK; ++blk) {
+                            i32x4 a8[NS];
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) {
+                                const int row = ((int) sub0 + i) * 16 + li;
+                                a8[i] = __builtin_bit_cast(i32x4, img[row * SR + ((blk * 4 + kq) ^ (row & (SR - 1)))]);
+                            }
+#pragma unroll
+                            for (int i = 0; i < NS; ++i) acc8[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a8[i], b8[blk], acc8[i], 0, 0, 0);
+                        }
+                    }
+                } else if (gact && !(VSR_ABLATE & 4)) {
 #pragma unroll
                     for (int h0 = 0; h0 < NS; h0 += NH)
 #pragma unroll
@@ -405,6 +437,11 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
             do_stage(std::integral_constant<int, 0>{});
             if constexpr (NCH > 1) do_stage(std::integral_constant<int, 1>{});
             if constexpr (NCH > 2) do_stage(std::integral_constant<int, 2>{});
+            if constexpr (I8) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    acc[i] = f32x4{(float) acc8[i][0], (float) acc8[i][1], (float) acc8[i][2], (float) acc8[i][3]};
+            }
 
             // results: acc[i][r] = dot(row slot (sub0 + i) * 16 + kq * 4 + r, query column jq of the wave's group).  Every
             // lane screens its pairs, reserves room in its query's buffer for all of its survivors with ONE returning
@@ -516,7 +553,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
 template <int METRIC>
 hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
 {
-    const uint32_t nch = p.pstride4 / MW_S;
+    const uint32_t nch = p.plane_ho == 2 ? 1u : p.pstride4 / MW_S;
     const size_t lds = mfmaw_lds_bytes();
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
@@ -531,12 +568,17 @@ hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream
     auto pick = [&](auto nchc) -> hipError_t {
         constexpr int N = decltype(nchc)::value;
         constexpr int D = mw_depth(N);
-        if (p.plane_ho) {
-            if constexpr (N <= 2)                                              // hi-only: 128 floats per stage, d <= 192 -> <= 2 stages
-                return sample ? launch(mfma_wide_kernel<METRIC, N, true, true, D>) : launch(mfma_wide_kernel<METRIC, N, false, true, D>);
+        if (p.plane_ho == 2) {
+            if constexpr (N == 1 && METRIC == M_L2)                            // int8 planes: d <= 128, L2
+                return sample ? launch(mfma_wide_kernel<METRIC, 1, true, 2, D>) : launch(mfma_wide_kernel<METRIC, 1, false, 2, D>);
             return hipErrorInvalidValue;
         }
-        return sample ? launch(mfma_wide_kernel<METRIC, N, true, false, D>) : launch(mfma_wide_kernel<METRIC, N, false, false, D>);
+        if (p.plane_ho) {
+            if constexpr (N <= 2)                                              // hi-only: 128 floats per stage, d <= 192 -> <= 2 stages
+                return sample ? launch(mfma_wide_kernel<METRIC, N, true, 1, D>) : launch(mfma_wide_kernel<METRIC, N, false, 1, D>);
+            return hipErrorInvalidValue;
+        }
+        return sample ? launch(mfma_wide_kernel<METRIC, N, true, 0, D>) : launch(mfma_wide_kernel<METRIC, N, false, 0, D>);
     };
     switch (nch) {
     case 1: return pick(std::integral_constant<int, 1>{});

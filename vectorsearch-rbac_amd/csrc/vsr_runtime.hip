@@ -122,6 +122,10 @@ struct vsr_ctx {
     DevBuf d_tau;        // seeded thresholds (sample pass)
     DevBuf d_samp;       // K2w: per-query sample buffers
     DevBuf d_qcnt;       // K2w: [candidate counts | sample counts]
+    bool   hint_u8 = false;       // vsr_set_query_hint: the caller's DEVICE-resident queries are integers 0..255
+    bool   int8_this_call = false;   // search_impl -> make_plan: the queries of this call qualify for the int8 planes
+    bool   q8_ok = true;          // ... and every hinted query so far really was (else the hint is dropped)
+    PinBuf h_q8;                  // one word the staging kernel sets when a query is not (read without synchronising)
     bool   no_fused = false;      // VSR_NO_FUSED: nq == 1 takes the general path (staging, K1, K5)
     bool   seeding = true;        // seed thresholds of big shared passes from a 1/32 sample pass
     int64_t seed_min_rows = 2000000;
@@ -221,6 +225,8 @@ struct vsr_corpus {
     uint2*      d_all_tiles = nullptr;   // identity tile list (K2w always walks an explicit list: unfiltered passes use this)
     uint32_t    pstride4 = 0;            // 16-byte chunks per plane row
     bool        scr_has_mid = true;      // false: every element is exactly a bf16 value (e.g. SIFT's 0..255 integers)
+    uint4*      d_scr8 = nullptr;        // int8 planes (x - 128, 128 bytes per row): corpus of integers 0..255, d <= 128; L2 only
+    float*      d_norm2_8 = nullptr;     // sum (x - 128)^2 per row
     float*      d_norm2_max = nullptr;   // max |row|^2 (error bound of K2 screening); +Inf if any |row|^2 is not finite
     bool        k2_safe = true;          // false: some |row|^2 is Inf / NaN (non-finite or huge elements) -> exact kernels only
     int64_t*    d_block = nullptr;
@@ -449,7 +455,7 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
 vsr_corpus::~vsr_corpus()
 {
     drop_cached_filters(this);
-    void* ptrs[] = {d_rows, d_scr, d_all_tiles, d_doc_class, d_rank, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
+    void* ptrs[] = {d_rows, d_scr, d_scr8, d_norm2_8, d_all_tiles, d_doc_class, d_rank, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
     for (void* p : ptrs)
         if (p) (void) hipFree(p);
 }
@@ -565,6 +571,20 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
             HIPCHK(hipMalloc(&c->d_all_tiles, all.size() * sizeof(uint2)));
             HIPCHK(hipMemcpy(c->d_all_tiles, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
             HIPCHK(hipStreamSynchronize(ctx->stream));
+            // SIFT-like corpora (every element an integer 0..255, d <= 128) also get int8 planes: a quarter of the fp32
+            // bytes per row and v_mfma_i32_16x16x64_i8; used for L2 searches whose queries are such integers too
+            if (!c->scr_has_mid && dim <= 128 && !getenv("VSR_NO_INT8")) {
+                HIPCHK(hipMemsetAsync(d_any, 0, sizeof(uint32_t), ctx->stream));
+                HIPCHK(launch_check_u8_exact(c->d_rows, (uint32_t) n, c->stride4, d_any, ctx->stream));
+                HIPCHK(hipMemcpyAsync(&any, d_any, sizeof any, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                if (any == 0) {
+                    HIPCHK(hipMalloc(&c->d_scr8, alloc_rows * (size_t) 128 + 1024));
+                    HIPCHK(hipMalloc(&c->d_norm2_8, alloc_rows * sizeof(float)));
+                    HIPCHK(launch_split_planes8(c->d_rows, (uint32_t) n, c->stride4, (uint32_t) dim, c->d_scr8, c->d_norm2_8, ctx->stream));
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                }
+            }
         }
     }
     *out = c.release();
@@ -1035,6 +1055,7 @@ struct Plan {
     bool                     mq = false;     // shared passes run on K1m (vsr_mq.h)
     bool                     k2 = false;     // shared passes run on K2 / K2w (MFMA screening) + K5r
     bool                     k2w = false;    // ... on K2w: workgroup-shared row tiles, up to 128 queries per pass (vsr_mfmaw.h)
+    bool                     int8 = false;   // ... on the corpus's int8 planes (L2, integer 0..255 rows and queries)
     uint32_t                 keep = 0;       // partial list length kp (K2: 2k screening survivors; else k)
     uint32_t                 rerank_base = 0;  // K2: first partial list holding the per-query screening survivors
     uint32_t                 n_scan_lists = 0;
@@ -1060,7 +1081,7 @@ struct Plan {
     void reset()                             // keeps the vectors' capacity: one plan per batch, no allocation once warm
     {
         q_slots.clear(); groups.clear(); list_ids.clear(); block_map.clear(); n_launch = 0; sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
-        n_blocks = 0; qi = 1; mq = false; k2 = false; k2w = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
+        n_blocks = 0; qi = 1; mq = false; k2 = false; k2w = false; int8 = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
         n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0; sel_wave = false;
         scan_pairs = 0; unique_rows = 0; kp_frac = 0; sample_stride = 1;
     }
@@ -1205,6 +1226,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     plan.keep = plan.k2 ? keep : (uint32_t) k;
     if (plan.k2w) plan.qmax = 64;                           // query slots per workgroup: one 16-query group per wave
     else if (plan.k2) plan.qmax = plan.qmax > 16 ? 32 : 16;
+    plan.int8 = plan.k2w && c->d_scr8 && metric == VSR_METRIC_L2 && ctx->int8_this_call;
 
     int64_t total_rows = 0, total_cost = 0;
     for (auto& p : passes) {
@@ -1456,7 +1478,9 @@ static std::string scan_kernel_name(const Plan& plan, const vsr_corpus* c, int m
     static const char* mname[] = {"L2", "IP", "COSINE", "L1"};
     char buf[160];
     const uint32_t nstage = (c->stride4 + 15) / 16;
-    if (plan.k2w)
+    if (plan.k2w && plan.int8)
+        snprintf(buf, sizeof buf, "vsr::mfma_wide_kernel<%s, NCH=1, SAMPLE=false, PL=int8> (K2w, int8 planes)", mname[metric]);
+    else if (plan.k2w)
         snprintf(buf, sizeof buf, "vsr::mfma_wide_kernel<%s, NCH=%u, SAMPLE=false, HO=%s> (K2w, bf16 %s planes)", mname[metric],
                  c->pstride4 / 16, c->scr_has_mid ? "false" : "true", c->scr_has_mid ? "hi+mid" : "hi-only");
     else if (plan.k2)
@@ -1484,7 +1508,10 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     const size_t off_q = 0;
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
     const size_t off_qp = align_up(off_qn + (size_t) nq * sizeof(float), 256);
-    const size_t off_g = align_up(off_qp + (size_t) nq * q_pstride * 16, 256);             // copied from here on
+    const size_t off_q8 = align_up(off_qp + (size_t) nq * q_pstride * 16, 256);            // int8 query planes, |q-128|^2, validity
+    const size_t off_qn8 = align_up(off_q8 + (plan.int8 ? (size_t) nq * 128 : 0), 256);
+    const size_t off_qb = align_up(off_qn8 + (plan.int8 ? (size_t) nq * sizeof(float) : 0), 256);
+    const size_t off_g = align_up(off_qb + (plan.int8 ? (size_t) nq * sizeof(uint32_t) : 0), 256);    // copied from here on
     const size_t off_gs = align_up(off_g + plan.groups.size() * sizeof(ScanGroup), 256);
     const size_t off_qs = align_up(off_gs + plan.groups_s.size() * sizeof(ScanGroup), 256);
     const size_t off_sq = align_up(off_qs + plan.q_slots.size() * sizeof(uint32_t), 256);
@@ -1534,7 +1561,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     uint32_t* qcnt = ctx->d_qcnt.as<uint32_t>();
     uint32_t* scnt = qcnt + nq;
     {
-        StageParams st;
+        StageParams st{};
         const char* hd = reinterpret_cast<const char*>(ctx->h_desc.dp);
         st.src16 = reinterpret_cast<const uint4*>(hd + h_q_bytes);
         st.dst16 = reinterpret_cast<uint4*>(ds + off_g);
@@ -1553,6 +1580,16 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         st.tau = ctx->d_tau.as<uint64_t>();
         st.qcnt = qcnt;
         st.scnt = scnt;
+        if (plan.int8) {
+            if (!ctx->h_q8.p) {
+                if ((rc = ctx->h_q8.reserve(64))) return rc;
+                memset(ctx->h_q8.p, 0, 64);
+            }
+            st.q_scr8 = reinterpret_cast<uint4*>(ds + off_q8);
+            st.q_norm2_8 = reinterpret_cast<float*>(ds + off_qn8);
+            st.q8_bad = reinterpret_cast<uint32_t*>(ds + off_qb);
+            st.q8_bad_host = reinterpret_cast<uint32_t*>(ctx->h_q8.dp);
+        }
         HIPCHK(launch_stage(st, ctx->stream));
     }
     HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
@@ -1569,6 +1606,14 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     sp.q_scr = reinterpret_cast<const uint4*>(ds + off_qp);
     sp.pstride4 = c->pstride4;
     sp.plane_ho = c->scr_has_mid ? 0u : 1u;
+    if (plan.int8) {                                        // same kernel, int8 planes: 8 chunks per row, their own norms
+        sp.norm2 = c->d_norm2_8;
+        sp.q_norm2 = reinterpret_cast<const float*>(ds + off_qn8);
+        sp.scr = c->d_scr8;
+        sp.q_scr = reinterpret_cast<const uint4*>(ds + off_q8);
+        sp.pstride4 = 8;
+        sp.plane_ho = 2u;
+    }
     sp.q_slots = reinterpret_cast<const uint32_t*>(ds + off_qs);
     sp.kp = sp.k = kp;
     sp.qmax = plan.qmax;
@@ -1656,6 +1701,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     rr.qcnt = qcnt;
     rr.capq = GQ_CAP;
     rr.err_g = plane_err_g(c->dim);
+    rr.qbad = plan.int8 ? reinterpret_cast<const uint32_t*>(ds + off_qb) : nullptr;
     rr.seeded = 1;
     rr.tau_init = ctx->d_tau.as<uint64_t>();
     rr.out_flags = ctx->d_flags.as<int32_t>();
@@ -1690,6 +1736,24 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
             ctx->host_calls++;
         }
     } host_timer{ctx, h0};
+    // int8 planes (SIFT-like corpora): host queries are checked here; device-resident queries only under the caller's
+    // hint (vsr_set_query_hint), validated by the staging kernel -- a violating query is flagged, and the hint is dropped
+    // once the kernel's pinned word shows one (read without synchronising: at worst a batch late)
+    if (ctx->q8_ok && ctx->h_q8.p && *reinterpret_cast<volatile uint32_t*>(ctx->h_q8.p)) ctx->q8_ok = false;
+    ctx->int8_this_call = false;
+    if (c->d_scr8 && metric == VSR_METRIC_L2 && allow_screening) {
+        if (h_queries) {
+            bool ok = true;
+            const size_t total = (size_t) nq * dim;
+            for (size_t i = 0; i < total && ok; ++i) {
+                const float v = h_queries[i];
+                ok = v >= 0.0f && v <= 255.0f && v == floorf(v);
+            }
+            ctx->int8_this_call = ok;
+        } else {
+            ctx->int8_this_call = ctx->hint_u8 && ctx->q8_ok;
+        }
+    }
     static thread_local Plan plan;
     plan.reset();
     if (!make_plan(ctx, c, nq, k, metric, allow_screening, true, filters, plan)) {
@@ -1892,7 +1956,7 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     sp.n_groups = (uint32_t) plan.groups.size();
     sp.q_slots = reinterpret_cast<const uint32_t*>(ds + off_qs);
 
-    SelectParams sel;
+    SelectParams sel{};
     sel.partial = ctx->d_partial.as<uint64_t>();
     sel.list_ids = reinterpret_cast<const uint32_t*>(ds + off_li);
     sel.kp = kp;
@@ -2230,6 +2294,17 @@ extern "C" int vsr_last_scan_kernel(vsr_ctx* ctx, char* name, int name_len)
 {
     if (!ctx || !name || name_len < 1) return fail(VSR_ERR_INVALID, "vsr_last_scan_kernel: bad argument");
     snprintf(name, (size_t) name_len, "%s", ctx->last_kernel.c_str());
+    return VSR_OK;
+}
+
+extern "C" int vsr_set_query_hint(vsr_ctx* ctx, int u8_queries)
+{
+    if (!ctx) return fail(VSR_ERR_INVALID, "vsr_set_query_hint: ctx is NULL");
+    ctx->hint_u8 = u8_queries != 0;
+    if (ctx->hint_u8) {                                     // a fresh promise: forget earlier violations
+        ctx->q8_ok = true;
+        if (ctx->h_q8.p) *reinterpret_cast<volatile uint32_t*>(ctx->h_q8.p) = 0;
+    }
     return VSR_OK;
 }
 

@@ -50,6 +50,7 @@ SYMBOLS = {
     "vsr_search_device_on": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_search_device_exact": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_set_screening": (_i, [_vp, _i]),
+    "vsr_set_query_hint": (_i, [_vp, _i]),
     "vsr_screening_check": (_i, [_vp, C.POINTER(_i64), _vp, _i]),
     "vsr_merge_topk_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "vsr_packed_result_bytes": (_i64, [_i, _i]),

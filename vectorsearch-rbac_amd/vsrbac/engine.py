@@ -59,6 +59,11 @@ class Context:
             handle = int(stream_handle) or 1
         check(self._lib.vsr_set_stream(self._h, C.c_void_p(handle)))
 
+    def set_query_hint(self, u8_queries=True):
+        """Promise that the device-resident queries of this context are integers 0..255 (SIFT): L2 searches over a
+        corpus of such integers then screen on its int8 planes.  Verified on the device; a violation flags the query."""
+        check(self._lib.vsr_set_query_hint(self._h, 1 if u8_queries else 0))
+
     def synchronize(self):
         check(self._lib.vsr_synchronize(self._h))
 
