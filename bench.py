@@ -220,16 +220,26 @@ def main():
     # Two batches in flight: consecutive batches alternate between two sessions (contexts = stream + workspaces) over
     # the one resident corpus, so the selection / re-rank kernels of batch i run under the scan launch of batch i+1.
     n_sess = 1 if rehearsal else max(1, min(4, int(os.environ.get("VSR_BENCH_SESSIONS", "2"))))
-    nbuf = max(2 if overlap else 1, n_sess)           # one result record (and gathered buffer) per batch in flight
+    # The exchange is grouped: G consecutive batches share ONE record (laid out as one batch of G * nq queries), one
+    # all-gather and one merge launch -- fewer, larger collectives, and the host's per-step work (the pacing item once a
+    # shard step is down to ~0.15 ms) shrinks to the search call and two event operations.
+    G = max(1, int(os.environ.get("VSR_BENCH_EXCHANGE_EVERY", "4"))) if overlap else 1
+    n_gbuf = 3 if overlap else max(1, n_sess)         # group records in flight: filling, being exchanged, being merged
+                                                      # (no exchange: one record per batch in flight)
+    nbuf = n_gbuf * G
+    gq = G * nq
+    rec_g = ctx.packed_result_bytes(gq, k)
+    gk = gq * k
 
-    def views(pack):
-        return (pack[0:nk * 8].view(torch.int64).view(nq, k),            # raw u64 ordering keys
-                pack[nk * 8:nk * 16].view(torch.int64).view(nq, k),
-                pack[nk * 16:nk * 20].view(torch.int32).view(nq, k),
-                pack[nk * 20:nk * 24].view(torch.float32).view(nq, k))
+    def views(pack, j):                               # batch j's slices of a group record {keys, block, doc, dist}[G * nq][k]
+        lo, hi = j * nk, (j + 1) * nk
+        return (pack[0:gk * 8].view(torch.int64)[lo:hi].view(nq, k),     # raw u64 ordering keys
+                pack[gk * 8:gk * 16].view(torch.int64)[lo:hi].view(nq, k),
+                pack[gk * 16:gk * 20].view(torch.int32)[lo:hi].view(nq, k),
+                pack[gk * 20:gk * 24].view(torch.float32)[lo:hi].view(nq, k))
 
-    d_packs = [torch.empty((rec,), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    d_views = [views(pk) for pk in d_packs]
+    d_packs = [torch.empty((rec_g,), dtype=torch.uint8, device=dev) for _ in range(n_gbuf)]
+    d_views = [views(d_packs[b // G], b % G) for b in range(nbuf)]
     d_rows = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(nbuf)]
     d_cnts = [torch.empty((nq,), dtype=torch.int32, device=dev) for _ in range(nbuf)]
     s_main = torch.cuda.current_stream()
@@ -239,60 +249,74 @@ def main():
         cx = vsrbac.Context(local_rank)
         cx.set_stream(sx.cuda_stream)
         sessions.append(cx)
+        s_scan.append(sx)
     # SIFT queries are uint8 like the corpus (the query vectors are corpus rows, read_dataset_function.py:736-737): the
     # library is told so and verifies it per query on the device (vsr_set_query_hint; a violation would flag and abort)
     if os.environ.get("VSR_BENCH_NO_U8_HINT") != "1":
-        for sx in sessions:
-            sx.set_query_hint(True)
-        s_scan.append(sx)
+        for sess in sessions:
+            sess.set_query_hint(True)
     if parts > 1:
-        g_packs = [torch.full((parts * rec,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(nbuf)]   # [parts] records
-        m_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
-        m_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
-        m_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
-        m_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
-        m_keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        g_packs = [torch.full((parts * rec_g,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(n_gbuf)]   # [parts] group records
+        m_blk = torch.empty((gq, k), dtype=torch.int64, device=dev)
+        m_doc = torch.empty((gq, k), dtype=torch.int32, device=dev)
+        m_dist = torch.empty((gq, k), dtype=torch.float32, device=dev)
+        m_cnt = torch.empty((gq,), dtype=torch.int32, device=dev)
+        m_keys = torch.empty((gq, k), dtype=torch.int64, device=dev)
     if overlap:
         s_comm = torch.cuda.Stream(device=dev)
         mctx = vsrbac.Context(local_rank)                         # the merge runs on the exchange stream
         mctx.set_stream(s_comm.cuda_stream)
-        ev_scan = [torch.cuda.Event() for _ in range(nbuf)]       # record b holds the results of its batch
-        ev_sent = [torch.cuda.Event() for _ in range(nbuf)]       # record b has been read by the exchange
-    state = {"i": 0, "overlap": overlap, "n_sess": n_sess, "leg": legs[0]}
+        ev_scan = [torch.cuda.Event() for _ in range(nbuf)]       # slot b of its group record holds the results of its batch
+        ev_sent = [torch.cuda.Event() for _ in range(n_gbuf)]     # group record g has been read by the exchange
+    state = {"i": 0, "overlap": overlap, "n_sess": n_sess, "leg": legs[0], "open": 0}
+
+    def exchange_group(gb, filled):
+        """All-gather + merge of group record gb (its first `filled` batches are new) on the exchange stream."""
+        with torch.cuda.stream(s_comm):
+            for j in range(filled):
+                s_comm.wait_event(ev_scan[gb * G + j])
+            if world > 1:
+                dist.all_gather_into_tensor(g_packs[gb], d_packs[gb])     # RCCL over xGMI: G * nq * k * 24 bytes per rank
+            else:
+                g_packs[gb][0:rec_g].copy_(d_packs[gb], non_blocking=True)
+            ev_sent[gb].record(s_comm)
+            mctx.merge_topk_packed_device(ptr(g_packs[gb]), parts, gq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist),
+                                          ptr(m_keys), ptr(m_cnt))
+
+    def finish_groups():
+        """A partly filled group record at the end of a run of steps is exchanged as it is."""
+        if state["overlap"] and state["open"]:
+            exchange_group(((state["i"] - 1) // G) % n_gbuf, state["open"])
+            state["open"] = 0
 
     def step():
         i = state["i"]
         state["i"] += 1
         overlap, n_sess = state["overlap"], state["n_sess"]
-        b = i % nbuf
+        b = i % nbuf                                             # slot b % G of group record b // G
         qb = i % nb                                              # this step's query batch
         keys_b, blk_b, doc_b, dist_b = d_views[b]
-        sess, st = sessions[b % n_sess], s_scan[b % n_sess]
+        sess, st = sessions[i % n_sess], s_scan[i % n_sess]
         if overlap and i >= nbuf:
-            st.wait_event(ev_sent[b])                             # the batch that used record b before has left it
+            st.wait_event(ev_sent[b // G])                        # the exchange that read this group record before is done
         corpus.search_device(ptr(d_qs[qb]), nq, k, "l2", filt[state["leg"]][qb], ptr(blk_b), ptr(doc_b), ptr(d_rows[b]),
                              ptr(dist_b), ptr(d_cnts[b]), ptr(keys_b), session=sess)
         if world > 1 and rehearsal:
             torch.cuda.synchronize()
-            hg = torch.empty((world * rec,), dtype=torch.uint8)
+            hg = torch.empty((world * rec_g,), dtype=torch.uint8)
             dist.all_gather_into_tensor(hg, d_packs[0].cpu())
             g_packs[0].copy_(hg)
             ctx.merge_topk_packed_device(ptr(g_packs[0]), world, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist), ptr(m_keys),
                                          ptr(m_cnt))
         elif overlap:
             ev_scan[b].record(st)
-            with torch.cuda.stream(s_comm):
-                s_comm.wait_event(ev_scan[b])
-                if world > 1:
-                    dist.all_gather_into_tensor(g_packs[b], d_packs[b])   # RCCL over xGMI: nq*k*24 bytes per rank
-                else:
-                    g_packs[b][0:rec].copy_(d_packs[b], non_blocking=True)
-                ev_sent[b].record(s_comm)
-                mctx.merge_topk_packed_device(ptr(g_packs[b]), parts, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist),
-                                              ptr(m_keys), ptr(m_cnt))
-        elif world > 1:                                           # plain loop: scan, exchange, merge on one stream
-            dist.all_gather_into_tensor(g_packs[b], d_packs[b])
-            ctx.merge_topk_packed_device(ptr(g_packs[b]), parts, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist),
+            state["open"] += 1
+            if state["open"] == G:
+                exchange_group(b // G, G)
+                state["open"] = 0
+        elif world > 1:                                           # plain loop (G = 1): scan, exchange, merge on one stream
+            dist.all_gather_into_tensor(g_packs[0], d_packs[0])
+            ctx.merge_topk_packed_device(ptr(g_packs[0]), parts, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist),
                                          ptr(m_keys), ptr(m_cnt))
 
     def barrier():
@@ -323,13 +347,14 @@ def main():
         try:
             for _ in range(warmup):
                 step()
+            finish_groups()
             barrier()
         except Exception as exc:                      # never lose the run to the overlapped choreography
             if not (state["overlap"] or state["n_sess"] > 1):
                 raise
             print(f"[bench] overlapped loop failed in warm-up ({exc!r}); falling back to one batch in flight, serial "
                   f"exchange", file=sys.stderr, flush=True)
-            state["overlap"], state["n_sess"] = False, 1
+            state["overlap"], state["n_sess"], state["open"] = False, 1, 0
             torch.cuda.synchronize()
             for _ in range(warmup):
                 step()
@@ -341,6 +366,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(steps):
             step()
+        finish_groups()
         t_enq = time.perf_counter() - t1              # host time to enqueue the whole run (must stay below dt)
         barrier()
         dt = reduce_max(time.perf_counter() - t1)
@@ -355,18 +381,17 @@ def main():
                     st[key] = [a + b for a, b in zip(st[key], one[key])]
         sim_ok = None
         if sim_world > 1:      # development check of the overlapped choreography on one GPU: merged == local
-            last = d_views[(state["i"] - 1) % nbuf]
-            sim_ok = bool(torch.equal(m_keys, last[0]) and torch.equal(m_blk, last[1]) and torch.equal(m_dist, last[3]))
+            lb = (state["i"] - 1) % nbuf                 # the last batch: slot lb % G of the last group record
+            last = d_views[lb]
+            sl = slice((lb % G) * nq, (lb % G + 1) * nq)
+            mk, mb, md = m_keys[sl], m_blk[sl], m_dist[sl]
+            sim_ok = bool(state["overlap"] and torch.equal(mk, last[0]) and torch.equal(mb, last[1]) and torch.equal(md, last[3]))
             if not sim_ok:
-                bad = ((m_keys != last[0]) | (m_blk != last[1]) | (m_dist != last[3])).any(dim=1)
-                gp = g_packs[(state["i"] - 1) % nbuf]
+                bad = ((mk != last[0]) | (mb != last[1]) | (md != last[3])).any(dim=1)
+                gp = g_packs[lb // G]
                 print(f"[bench] simulated exchange: {int(bad.sum())} of {nq} queries differ after the merge "
                       f"(first {bad.nonzero()[:4].flatten().tolist()}); gathered part 0 == record: "
-                      f"{bool(torch.equal(gp[0:rec], d_packs[(state['i'] - 1) % nbuf]))}; other parts empty: "
-                      f"{bool((gp[rec:rec + nk * 8] == 0xFF).all())}; keys/blk/dist differ: "
-                      f"{int((m_keys != last[0]).any(dim=1).sum())}/{int((m_blk != last[1]).any(dim=1).sum())}/"
-                      f"{int((m_dist != last[3]).any(dim=1).sum())}; q{int(bad.nonzero()[0])}: merged "
-                      f"{m_blk[int(bad.nonzero()[0])][:6].tolist()} local {last[1][int(bad.nonzero()[0])][:6].tolist()}",
+                      f"{bool(torch.equal(gp[0:rec_g], d_packs[lb // G]))}; overlapped loop ran: {state['overlap']}",
                       file=sys.stderr, flush=True)
         return {"dt": dt, "t_enq": t_enq, "stats": st, "flagged": flagged() - before,
                 "kernel": sessions[0].last_scan_kernel(), "sim_ok": sim_ok}
@@ -558,8 +583,9 @@ def main():
             print(json.dumps(out), flush=True)
             raise SystemExit("parity spot check failed: GPU results differ from the oracle")
     if parts > 1:
-        out["config"]["exchange"] = ("all-gather + merge of batch i overlapped with the scan of batch i+1 (second stream)"
-                                     if state["overlap"] else "serial (rehearsal through host memory)")
+        out["config"]["exchange"] = (f"one all-gather + merge per {G} batches on a second stream, overlapped with the "
+                                     f"scans of the next batches" if state["overlap"] else
+                                     "serial (rehearsal through host memory)" if rehearsal else "serial, one per batch")
     if sim_world > 1:
         out["sim_world"] = {"parts": parts, "merged_equals_local": bool(all(r["sim_ok"] for r in results.values()))}
     if rank == 0 and world > 1 and os.environ.get("VSR_BENCH_VERIFY") == "1":

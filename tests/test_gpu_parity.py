@@ -170,7 +170,8 @@ def test_screening_gap_inside_error_bound_falls_back_to_exact(ctx, oracle):
     2k-th candidate ties with the k-th result the re-rank cannot prove exactness: the query must be flagged and re-run
     on the exact path, and the answer must still follow the (distance, document_id, block_id) order."""
     rng = np.random.default_rng(12)
-    base = sift_like(rng, 8)
+    base = 2.0 * sift_like(rng, 8)                       # even integers up to 510: exact in bf16, but not 0..255, so the
+                                                         # int8 planes (exact screening, nothing to flag) do not apply
     x = np.repeat(base, 300, axis=0)                     # every vector 300 times: ties far beyond 2k = 200
     x = x[rng.permutation(x.shape[0])]
     n = x.shape[0]
@@ -198,7 +199,8 @@ def test_device_api_flags_cannot_be_ignored_and_exact_variant_reruns(ctx, oracle
     vsr_search_device_exact waits, re-runs the flagged queries on the exact path and patches the outputs."""
     import torch
     rng = np.random.default_rng(12)
-    base = sift_like(rng, 8)
+    base = 2.0 * sift_like(rng, 8)                       # even integers up to 510: exact in bf16, but not 0..255, so the
+                                                         # int8 planes (exact screening, nothing to flag) do not apply
     x = np.repeat(base, 300, axis=0)                     # every vector 300 times: ties far beyond 2k = 200
     x = x[rng.permutation(x.shape[0])]
     n = x.shape[0]

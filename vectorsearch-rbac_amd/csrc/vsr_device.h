@@ -184,6 +184,7 @@ struct RerankParams {
     uint32_t           capq;
     float              err_g;          // relative error bound of the screening dot product: |dot_s - dot| <= err_g |x| |q|
     const uint32_t*    qbad;           // [n_slots] != 0: the query's screening input was invalid (int8 path): flag it
+    uint32_t           exact_screen;   // int8 planes: screening values are the exact distances, no re-rank, kp = k
     int                seeded;         // thresholds were seeded from a sample: also check completeness
     const uint64_t*    tau_init;       // [n_slots] the seeds (bound on every excluded row when the list is not full)
     int32_t*           out_flags;      // [n_queries] by out_slot: 1 = screening gap inside the error bound

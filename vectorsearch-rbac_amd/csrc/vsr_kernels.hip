@@ -894,7 +894,9 @@ __device__ __forceinline__ void rerank_body(const RerankParams& p, uint32_t slot
     // overwrite the screening keys slot by slot: every slot is read by the half-wave that later writes it
     const int half = lane >> 5, hl = lane & 31;
     constexpr int U = 4;                                                   // candidates in flight per half-wave
-    for (uint32_t c0 = (uint32_t) wave * 2 * U; c0 < np2; c0 += 4 * 2 * U) {
+    // (int8 planes: the screening value IS the exact fp32 distance -- integer sums below 2^24 -- so there is nothing to
+    // recompute and no gap to prove: the kp = k smallest screening keys are the answer)
+    for (uint32_t c0 = p.exact_screen ? np2 : (uint32_t) wave * 2 * U; c0 < np2; c0 += 4 * 2 * U) {
         uint64_t sk[U];
         float s[U], nx[U];
 #pragma unroll
@@ -968,7 +970,7 @@ __device__ __forceinline__ void rerank_body(const RerankParams& p, uint32_t slot
             const uint32_t allowed = p.queries[slot].allowed;
             if (lo < p.k) {
                 if (lo < allowed) flag = 1;                                // the threshold cut below the k-th result
-            } else {
+            } else if (!p.exact_screen) {
                 const float a_last = mono_to_float((uint32_t) (bound >> 32));
                 const float d_k = mono_to_float((uint32_t) (keys[p.k - 1] >> 32));
                 const float g = p.err_g;                                   // relative error of the screening dot product

@@ -1227,6 +1227,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     if (plan.k2w) plan.qmax = 64;                           // query slots per workgroup: one 16-query group per wave
     else if (plan.k2) plan.qmax = plan.qmax > 16 ? 32 : 16;
     plan.int8 = plan.k2w && c->d_scr8 && metric == VSR_METRIC_L2 && ctx->int8_this_call;
+    if (plan.int8) plan.keep = (uint32_t) std::max(k, 32);  // exact screening: no second half of survivors to re-rank
 
     int64_t total_rows = 0, total_cost = 0;
     for (auto& p : passes) {
@@ -1342,7 +1343,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
             const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
             if (t64 > 0) frac = std::max(frac, sampled / t64);
         }
-        const double lambda = (double) keep * frac;
+        const double lambda = (double) plan.keep * frac;
         const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
         plan.kp_frac = (float) lambda;
         bool ok = seed_m <= GQ_SAMPLE_CAP / 4;
@@ -1702,6 +1703,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     rr.capq = GQ_CAP;
     rr.err_g = plane_err_g(c->dim);
     rr.qbad = plan.int8 ? reinterpret_cast<const uint32_t*>(ds + off_qb) : nullptr;
+    rr.exact_screen = plan.int8 ? 1u : 0u;
     rr.seeded = 1;
     rr.tau_init = ctx->d_tau.as<uint64_t>();
     rr.out_flags = ctx->d_flags.as<int32_t>();
