@@ -238,10 +238,10 @@ inline int mfma_qmax(uint32_t stride4) { (void) stride4; return 32; }
 // K2w (vsr_mfmaw.h): GEMM-shaped shared passes for rows of <= 256 floats -- one 64-row tile staged per WORKGROUP and
 // multiplied against up to 64 (128 at d <= 128) queries whose B fragments live in the four waves' registers.
 constexpr uint32_t MW_PEND = 256;                       // survivors a wave parks in LDS between two flushes (vsr_mfmaw.h)
-inline size_t mfmaw_lds_bytes()
+inline size_t mfmaw_lds_bytes(bool int8 = false)
 {
-    // two 64-row x 16-chunk stage buffers + the row-mapping ring + per wave {value, row, slot}[MW_PEND]
-    return (size_t) 2 * 64 * 16 * 16 + 8 * 64 * 8 + (size_t) 4 * MW_PEND * 12;
+    // two 64-row stage buffers (16 chunks per row; int8 planes: 8) + the row-mapping ring + per wave {value, row, column}[MW_PEND]
+    return (size_t) 2 * 64 * (int8 ? 8 : 16) * 16 + 8 * 64 * 8 + (size_t) 4 * MW_PEND * 12;
 }
 constexpr uint32_t GQ_CAP = 16384;                      // candidate keys per query (a filter this small needs no threshold at all)
 constexpr uint32_t GQ_SAMPLE_CAP = 4096;                // sampled minima per query kept for the threshold seed (more: dropped)

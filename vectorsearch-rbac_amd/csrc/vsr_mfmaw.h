@@ -67,7 +67,17 @@ constexpr int MW_RING = 8;                 // row-mapping ring (tiles): >= DEPTH
 #define VSR_ABLATE 0
 #endif
 constexpr int mw_depth(int nch) { return nch == 1 ? VSR_MW_DEPTH1 : nch == 2 ? 2 : 1; }
-constexpr int mw_occ(int nch) { return nch == 1 ? VSR_MW_OCC1 : 2; }
+// (a deeper register ring for the sample pass -- all of a workgroup's few tiles in flight at once -- was measured: the
+// occupancy it costs outweighs it: 72 -> 115 us)
+constexpr int mw_sample_depth(int nch, int pl) { (void) pl; return mw_depth(nch); }
+#ifndef VSR_MW_OCC8
+#define VSR_MW_OCC8 4
+#endif
+constexpr int mw_occ(int nch, int pl = 0, bool sample = false)
+{
+    (void) sample;
+    return pl == 2 ? VSR_MW_OCC8 : nch == 1 ? VSR_MW_OCC1 : 2;
+}   // int8: 32 KB of LDS, ~120 VGPRs
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases global memory, and since gfx950 counts
 // stores and loads in the one vmcnt queue that costs an s_waitcnt vmcnt(0): every prefetched row load would be drained at
@@ -84,7 +94,7 @@ __device__ __forceinline__ void lds_barrier()
 // queries, elements stored as x - 128; L2 only: |x' - q'|^2 = |x - q|^2, exact in int32 / fp32; 128 bytes per row, the
 // tile image has 8 chunks per row and v_mfma_i32_16x16x64_i8 covers d = 128 in two instructions).
 template <int METRIC, int NCH, bool SAMPLE, int PL, int DEPTH>
-__global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(const ScanParams p)
+__global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide_kernel(const ScanParams p)
 {
     constexpr bool HO = PL == 1, I8 = PL == 2;
     constexpr int SR = I8 ? 8 : MW_S;                                          // 16-byte chunks per row and stage
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
 
     // LDS: [stage buffers | row index ring | |row|^2 ring]
     uint4*    stage = reinterpret_cast<uint4*>(smem);                           // [2][64 * MW_S]
-    unsigned char* after = smem + 2 * MW_ROWS * MW_S * 16;
+    unsigned char* after = smem + 2 * MW_ROWS * SR * 16;
     int32_t*  rowidx = reinterpret_cast<int32_t*>(after);                       // [MW_RING][64]
     float*    rownorm = reinterpret_cast<float*>(after + MW_RING * 64 * 4);     // [MW_RING][64]
     unsigned char* pend = after + MW_RING * 64 * 8;                             // parked survivors, per wave
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH)) void mfma_wide_kernel(cons
 
             auto do_stage = [&](auto sc) {
                 constexpr int S = decltype(sc)::value;
-                uint4* img = stage + (size_t) buf * (MW_ROWS * MW_S);
+                uint4* img = stage + (size_t) buf * (MW_ROWS * SR);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int slot = u * LROWS + lrow;
@@ -554,7 +564,7 @@ template <int METRIC>
 hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
 {
     const uint32_t nch = p.plane_ho == 2 ? 1u : p.pstride4 / MW_S;
-    const size_t lds = mfmaw_lds_bytes();
+    const size_t lds = mfmaw_lds_bytes(p.plane_ho == 2);
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -570,15 +580,15 @@ hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream
         constexpr int D = mw_depth(N);
         if (p.plane_ho == 2) {
             if constexpr (N == 1 && METRIC == M_L2)                            // int8 planes: d <= 128, L2
-                return sample ? launch(mfma_wide_kernel<METRIC, 1, true, 2, D>) : launch(mfma_wide_kernel<METRIC, 1, false, 2, D>);
+                return sample ? launch(mfma_wide_kernel<METRIC, 1, true, 2, mw_sample_depth(1, 2)>) : launch(mfma_wide_kernel<METRIC, 1, false, 2, D>);
             return hipErrorInvalidValue;
         }
         if (p.plane_ho) {
             if constexpr (N <= 2)                                              // hi-only: 128 floats per stage, d <= 192 -> <= 2 stages
-                return sample ? launch(mfma_wide_kernel<METRIC, N, true, 1, D>) : launch(mfma_wide_kernel<METRIC, N, false, 1, D>);
+                return sample ? launch(mfma_wide_kernel<METRIC, N, true, 1, mw_sample_depth(N, 1)>) : launch(mfma_wide_kernel<METRIC, N, false, 1, D>);
             return hipErrorInvalidValue;
         }
-        return sample ? launch(mfma_wide_kernel<METRIC, N, true, 0, D>) : launch(mfma_wide_kernel<METRIC, N, false, 0, D>);
+        return sample ? launch(mfma_wide_kernel<METRIC, N, true, 0, mw_sample_depth(N, 0)>) : launch(mfma_wide_kernel<METRIC, N, false, 0, D>);
     };
     switch (nch) {
     case 1: return pick(std::integral_constant<int, 1>{});
