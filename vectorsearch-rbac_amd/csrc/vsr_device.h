@@ -114,6 +114,7 @@ struct ScanParams {
                                    // identity.  Set for list-ordered views (IVF): see vsr_corpus::base
     const uint64_t*  ones;         // one all-ones 64-bit word (the "bitmap" of passes without a permission bitmap)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
+    uint32_t         epi;          // K2w main launch, L2: 1 = few survivors expected per wave-tile (mask epilogue), 0 = rounds
     FusedTail        fused;        // K1, nq == 1 only (enable = 0 otherwise)
 };
 

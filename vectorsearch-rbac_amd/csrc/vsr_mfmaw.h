@@ -93,7 +93,7 @@ __device__ __forceinline__ void lds_barrier()
 // PL: plane kind of the corpus (ScanParams::plane_ho): 0 = bf16 hi + mid, 1 = bf16 hi only, 2 = int8 (u8-exact corpus and
 // queries, elements stored as x - 128; L2 only: |x' - q'|^2 = |x - q|^2, exact in int32 / fp32; 128 bytes per row, the
 // tile image has 8 chunks per row and v_mfma_i32_16x16x64_i8 covers d = 128 in two instructions).
-template <int METRIC, int NCH, bool SAMPLE, int PL, int DEPTH>
+template <int METRIC, int NCH, bool SAMPLE, int PL, int DEPTH, int EPI = 0>
 __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide_kernel(const ScanParams p)
 {
     constexpr bool HO = PL == 1, I8 = PL == 2;
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
         if (row >= 0 && !((bw >> ((uint32_t) row & 63u)) & 1ull)) row = -1;
         if (wave == 0) {
             rowidx[(it_ % MW_RING) * 64 + lane] = row;
-            rownorm[(it_ % MW_RING) * 64 + lane] = row >= 0 ? nrm : 0.0f;
+            rownorm[(it_ % MW_RING) * 64 + lane] = row >= 0 ? nrm : __builtin_nanf("");   // NaN: an invalid slot's L2 value is NaN
+                                                                                          // and fails every `<=` (fast path below)
         }
     };
     {
@@ -351,8 +352,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
         f_n = 0;
     };
     // one entry per lane with `has` (wave-uniform call): the position is the wave's running count + the lane's rank
-    auto park = [&](bool has, uint32_t key_hi, uint32_t row) {
-        const uint64_t act = __ballot(has);
+    auto park_mask = [&](uint64_t act, bool has, uint32_t key_hi, uint32_t row) {
         const uint32_t room = MW_PEND - (p_tail - p_head);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) act, 0u));
         if (has) {
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
         const uint32_t n_act = (uint32_t) __popcll(act);
         p_tail += n_act < room ? n_act : room;
     };
+    auto park = [&](bool has, uint32_t key_hi, uint32_t row) { park_mask(__ballot(has), has, key_hi, row); };
 
     auto run = [&](auto nsc) {
         constexpr int NS = decltype(nsc)::value;                   // 16-row sub-tiles of this wave (1, 2 or 4)
@@ -462,6 +463,40 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
 #pragma unroll
                 for (int i = 0; i < NS; ++i) sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
                 if (sink == 12345.678f) atomicOr(p.err, 2u);
+            } else if (EPI == 1 && METRIC == M_L2 && !SAMPLE && !(VSR_ABLATE & 1)) {
+                // L2 main pass, FEW survivors per wave-tile (EPI = 1; the planner picks it when it expects <= 4, else the
+                // rounds below win): one compare per pair whose result is a lane mask in scalar registers -- an invalid row slot
+                // has |row|^2 = NaN in the ring, a pad column has the limit -inf, so `value <= limit` is the whole test
+                // (K2w corpora hold no NaN / Inf: vsr_corpus::k2_safe).  Survivors are then parked register by register:
+                // the value of register j is a compile-time operand, no select tree, and the loop is over the ~3 - 10
+                // survivors of the wave, not over lanes.
+                if (gact) {
+                    const int32_t* ridx = rowidx + (it % MW_RING) * 64;
+                    const float* rnrm = rownorm + (it % MW_RING) * 64;
+                    const float lim = qok ? tau_lim : -__builtin_inff();
+                    uint64_t m[NS * 4];
+                    uint64_t any = 0;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const int base = ((int) sub0 + i) * 16 + kq * 4;
+                        const float4 rn = *reinterpret_cast<const float4*>(&rnrm[base]);
+                        const float nx4[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            m[i * 4 + r] = __ballot(screen_value<METRIC>(acc[i][r], nx4[r], my_qn) <= lim);
+                            any |= m[i * 4 + r];
+                        }
+                    }
+                    if (any) {
+#pragma unroll
+                        for (int j = 0; j < NS * 4; ++j)
+                            if (m[j]) {                            // scalar test
+                                const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
+                                const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
+                                park_mask(m[j], (m[j] >> lane) & 1ull, mono_bits(v), (uint32_t) ridx[slot]);
+                            }
+                    }
+                }
             } else if (gact) {
                 const int32_t* ridx = rowidx + (it % MW_RING) * 64;
                 const float* rnrm = rownorm + (it % MW_RING) * 64;
@@ -575,20 +610,24 @@ hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream
         return hipGetLastError();
     };
     const bool sample = p.sample_stride > 1;
+    const bool few = !sample && METRIC == M_L2 && p.epi == 1;                  // survivor handling of the main launch (EPI)
     auto pick = [&](auto nchc) -> hipError_t {
         constexpr int N = decltype(nchc)::value;
         constexpr int D = mw_depth(N);
         if (p.plane_ho == 2) {
             if constexpr (N == 1 && METRIC == M_L2)                            // int8 planes: d <= 128, L2
-                return sample ? launch(mfma_wide_kernel<METRIC, 1, true, 2, mw_sample_depth(1, 2)>) : launch(mfma_wide_kernel<METRIC, 1, false, 2, D>);
+                return sample ? launch(mfma_wide_kernel<METRIC, 1, true, 2, mw_sample_depth(1, 2)>)
+                              : few ? launch(mfma_wide_kernel<METRIC, 1, false, 2, D, 1>) : launch(mfma_wide_kernel<METRIC, 1, false, 2, D>);
             return hipErrorInvalidValue;
         }
         if (p.plane_ho) {
             if constexpr (N <= 2)                                              // hi-only: 128 floats per stage, d <= 192 -> <= 2 stages
-                return sample ? launch(mfma_wide_kernel<METRIC, N, true, 1, mw_sample_depth(N, 1)>) : launch(mfma_wide_kernel<METRIC, N, false, 1, D>);
+                return sample ? launch(mfma_wide_kernel<METRIC, N, true, 1, mw_sample_depth(N, 1)>)
+                              : few ? launch(mfma_wide_kernel<METRIC, N, false, 1, D, METRIC == M_L2 ? 1 : 0>) : launch(mfma_wide_kernel<METRIC, N, false, 1, D>);
             return hipErrorInvalidValue;
         }
-        return sample ? launch(mfma_wide_kernel<METRIC, N, true, 0, mw_sample_depth(N, 0)>) : launch(mfma_wide_kernel<METRIC, N, false, 0, D>);
+        return sample ? launch(mfma_wide_kernel<METRIC, N, true, 0, mw_sample_depth(N, 0)>)
+                      : few ? launch(mfma_wide_kernel<METRIC, N, false, 0, D, METRIC == M_L2 ? 1 : 0>) : launch(mfma_wide_kernel<METRIC, N, false, 0, D>);
     };
     switch (nch) {
     case 1: return pick(std::integral_constant<int, 1>{});

@@ -1655,6 +1655,13 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
         sp.n_groups = (uint32_t) plan.groups.size();
         sp.sample_stride = 1;
+        {
+            // survivors a wave-tile (64 rows x 16 queries) can expect: what a query admits over the rows it scans
+            const double f = plan.kp_frac > 0 ? plan.kp_frac / kp : 1.0 / 16;
+            const double admitted = kp + 6.0 * std::sqrt(kp / f) + 4.0 / f;
+            const double rows_per_query = (double) plan.scan_pairs / std::max(1, nq);
+            sp.epi = rows_per_query > 0 && 1024.0 * admitted / rows_per_query <= 4.0 ? 1u : 0u;
+        }
         sp.tau_init = ctx->d_tau.as<uint64_t>();
         sp.qcand = ctx->d_cand.as<uint64_t>();
         sp.qcnt = qcnt;
