@@ -572,6 +572,30 @@ def main():
                 "kind": "port", "cores": 1, "m": 16, "ef_construction": 64, "rows": int(len(sub)), "build_s": round(build_s, 2),
                 "sweep": sweep, "sample": "pgvector's HNSW restated (oracle/vsr_index_oracle.c), first 30k rows of one role "
                                           "partition, 100 queries per ef_search, recall against the exact scan of those rows"}
+            # ... and the same graph searched by K4 on the GPU (vsr_hnsw_search: one wave per query), 1000 queries per call
+            try:
+                c2 = ctx.load_corpus(sub)
+                gidx = c2.load_hnsw(hidx.export())
+                gq = qvec[:1000]
+                gsweep = []
+                for ef, cpu_pt in zip((40, 200, 500), sweep):
+                    gidx.search(gq[:64], k, ef)                       # warm-up
+                    th = time.perf_counter()
+                    gres, _ = gidx.search(gq, k, ef)
+                    gs = time.perf_counter() - th
+                    cpu_rows = [hidx.search(hq[i], ef)[0][:k] for i in range(10)]
+                    same = all(np.array_equal(gres.rows[i][:len(cpu_rows[i])], cpu_rows[i]) for i in range(10))
+                    rec = float(np.mean([len(set(gres.rows[i][:int(gres.counts[i])].tolist()) & exact[i]) / max(1, len(exact[i]))
+                                         for i in range(len(hq))]))
+                    gsweep.append({"ef_search": ef, "qps": round(len(gq) / gs, 1), "recall_at_k": round(rec, 4),
+                                   "same_rows_as_cpu_port": bool(same)})
+                out["hnsw_gpu"] = {"kernel": "vsr::hnsw_search_kernel (K4)", "rows": int(len(sub)), "queries_per_call": int(len(gq)),
+                                   "sweep": gsweep, "note": "the graph of cpu_baseline.hnsw searched on the GPU through the host "
+                                                            "API (queries and results cross PCIe inside the timed call)"}
+                gidx.free()
+                c2.free()
+            except Exception as exc:
+                out["hnsw_gpu"] = {"error": repr(exc)}
         except Exception as exc:      # the baseline is reported, never required
             out["cpu_baseline"]["hnsw"] = {"error": repr(exc)}
         checks = {leg: spot_check(leg, orc, m) for leg in legs}
