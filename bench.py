@@ -519,6 +519,23 @@ def main():
                                     "kernel": ctx.last_scan_kernel(),
                                     "note": "one query per call, back to back on one stream; not the headline"}
 
+        # the boundary's host-buffer form (vsr_search: queries in, results out over PCIe, synchronous, flagged queries
+        # re-run inside the call), whole 1000-query batches; and the synchronous harness call, one query at a time
+        hq_np = allvec[0:nq]
+        hfil = list(filt[legs[0]][0]._keep)
+        corpus.search(hq_np, k, "l2", hfil)
+        th = time.perf_counter()
+        for _ in range(5):
+            corpus.search(hq_np, k, "l2", hfil)
+        th = (time.perf_counter() - th) / 5
+        t1q = time.perf_counter()
+        for i in range(50):
+            corpus.search(hq_np[i:i + 1], k, "l2", [hfil[i]])
+        t1q = (time.perf_counter() - t1q) / 50
+        out["host_buffers"] = {"ms_per_step": round(th * 1e3, 4), "qps": round(nq / th, 1),
+                               "one_query_per_call_ms": round(t1q * 1e3, 4),
+                               "note": "vsr_search with host pointers (PCIe inclusive, synchronous); never `value`"}
+
     # ---- CPU baseline (rank 0, N = 1): the oracle, pgvector's flags, one thread, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle
