@@ -651,6 +651,60 @@ def test_wide_shared_passes_exact(ctx, oracle, dim, nq):
     corpus.free()
 
 
+def test_one_query_per_call_is_one_launch_and_exact(ctx, oracle):
+    """nq == 1 (the reference harness's call shape): K1 + in-kernel merge tree + outputs in ONE launch.  Two merge levels
+    (600k rows -> hundreds of workgroup lists), ranges and bitmaps, k from 1 to 512 (8192 keys in the last merge at k = 256), a tie-saturated corpus (the radix
+    select has to break ties by row id), inner product, a filter with fewer than k rows, an empty filter, device and host
+    queries; k > 512 and cosine take the general path and still answer exactly."""
+    import torch
+    import vsrbac
+    rng = np.random.default_rng(77)
+    n, dim = 600_000, 128
+    base = sift_like(rng, 3000)
+    x = base[rng.integers(0, len(base), n)]              # every vector ~200 times: ties everywhere
+    blk, doc = _ids(n, 100)
+    corpus = ctx.load_corpus(x, blk, doc)
+    ndocs = int(doc.max())
+    perms = [(1, int(d)) for d in range(1, ndocs + 1, 3)] + [(2, 7)] + [(3, int(d)) for d in range(1, ndocs + 1)]
+    ur = [(1, 1), (2, 2), (3, 3), (4, 4)]                 # user 2 sees one document (100 rows), user 4 nothing
+    corpus.load_rbac(ur, perms)
+    q = base[5] + rng.integers(0, 3, dim).astype(np.float32)
+    for user, mode in ((1, vsrbac.RANGES), (1, vsrbac.BITMAP), (3, vsrbac.RANGES), (2, vsrbac.BITMAP), (4, vsrbac.RANGES)):
+        f = corpus.filter_for_user(user, mode)
+        mask = oracle.user_row_mask(user, ur, perms, doc)
+        for k in (1, 100, 256, 512):
+            res = corpus.search(q[None, :], k, "l2", [f])
+            if k <= 256:      # (k = 512 fuses only when the pass has few workgroups: two merge levels hold 8192 keys each)
+                assert "in-kernel merge" in ctx.last_scan_kernel(), ctx.last_scan_kernel()
+            _expect_exact(oracle, res, 0, "l2", x, q, k, doc, blk, mask)
+    res = corpus.search(q[None, :], 100, "ip")
+    assert "in-kernel merge" in ctx.last_scan_kernel()
+    _expect_exact(oracle, res, 0, "ip", x, q, 100, doc, blk)
+    res = corpus.search(q[None, :], 600, "l2")            # k > 512: staging + K1 + K5
+    assert "in-kernel merge" not in ctx.last_scan_kernel()
+    _expect_exact(oracle, res, 0, "l2", x, q, 600, doc, blk)
+    res = corpus.search(q[None, :], 50, "cosine")
+    assert "in-kernel merge" not in ctx.last_scan_kernel()
+    oidx, odist = oracle.filtered_topk("cosine", x, q, 50, doc, blk)
+    np.testing.assert_allclose(res.dist[0, :50], odist, rtol=TOL, atol=TOL)
+    # device-resident query, asynchronous call, twice in a row (the arrival counters must be back at zero)
+    dev = torch.device("cuda", 0)
+    k = 100
+    outs = (torch.empty((1, k), dtype=torch.int64, device=dev), torch.empty((1, k), dtype=torch.int32, device=dev),
+            torch.empty((1, k), dtype=torch.int64, device=dev), torch.empty((1, k), dtype=torch.float32, device=dev),
+            torch.empty((1,), dtype=torch.int32, device=dev))
+    d_q = torch.from_numpy(q[None, :].copy()).to(dev)
+    f = corpus.filter_for_user(1, vsrbac.RANGES)
+    mask = oracle.user_row_mask(1, ur, perms, doc)
+    for _ in range(2):
+        corpus.search_device(d_q.data_ptr(), 1, k, "l2", [f], *(t.data_ptr() for t in outs))
+        ctx.synchronize()
+        got = SimpleNamespace(block_ids=outs[0].cpu().numpy(), doc_ids=outs[1].cpu().numpy(), rows=outs[2].cpu().numpy(),
+                              dist=outs[3].cpu().numpy(), counts=outs[4].cpu().numpy())
+        _expect_exact(oracle, got, 0, "l2", x, q, k, doc, blk, mask)
+    corpus.free()
+
+
 def test_int8_planes_for_sift_like_queries(ctx, oracle):
     """A corpus of integers 0..255 (d <= 128) keeps int8 planes; L2 searches whose queries are such integers screen on
     them (v_mfma_i32_16x16x64_i8, exact).  Host queries are checked by the library; device-resident queries only under
