@@ -519,6 +519,24 @@ def main():
                                     "kernel": ctx.last_scan_kernel(),
                                     "note": "one query per call, back to back on one stream; not the headline"}
 
+        # the brute-force distance kernel on its own (north_star: ">= 60 % HBM roofline on the brute-force distance
+        # kernel"): K1, one unfiltered query over the whole corpus = every fp32 row once, HIP events on the launch stream
+        ctx.profiling(2)
+        ctx.stats_reset()
+        for i in range(10):
+            corpus.search_device(ptr(d_qs[0][i:i + 1]), 1, k, "l2", None, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
+                                 ptr(d_cnt), ptr(d_keys))
+        st1 = ctx.stats()
+        ctx.profiling(False)
+        if st1["scan_launches"][0]:
+            bf_ms = st1["scan_ms"][0] / st1["scan_launches"][0]
+            bf_bytes = (hi - lo) * (dim * 4) + k * 12
+            out["brute_force_scan"] = {"kernel": ctx.last_scan_kernel(), "rows": int(hi - lo), "bytes": int(bf_bytes),
+                                       "launch_ms": round(bf_ms, 4), "achieved_gbs": round(bf_bytes / bf_ms / 1e6, 1),
+                                       "frac_of_8TBs": round(bf_bytes / bf_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                       "note": "one query, no filter, fp32 rows (SURVEY 8d: rows * d * 4 + k * 12 bytes); the "
+                                               "launch includes the in-kernel merge of the workgroups' lists"}
+
         # the boundary's host-buffer form (vsr_search: queries in, results out over PCIe, synchronous, flagged queries
         # re-run inside the call), whole 1000-query batches; and the synchronous harness call, one query at a time
         hq_np = allvec[0:nq]
