@@ -54,3 +54,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle" not in text.lower() or f == "vsr_topk.h", os.path.join(base, f)
+
+
+def test_pg_shim_calls_only_declared_abi_functions():
+    """pg_shim/ cannot be compiled in this image (no postgres.h); at least every libvsrbac entry point it calls must be
+    one the header declares (and therefore one the library exports, see above), with the shim's own helpers defined."""
+    import glob
+    import re
+    with open(os.path.join(ROOT, "include", "vsrbac.h")) as f:
+        declared = set(re.findall(r"\b(vsr_[a-z0-9_]+)\s*\(", f.read()))
+    text = ""
+    for path in sorted(glob.glob(os.path.join(ROOT, "pg_shim", "*.[ch]"))):
+        with open(path) as f:
+            text += f.read()
+    called = set(re.findall(r"\b(vsr_[a-z0-9_]+)\s*\(", text))
+    own = set(re.findall(r"^(vsr_pg_[a-z0-9_]+)\s*\(", text, flags=re.M))          # the shim's own static functions
+    assert called - declared - own == set(), sorted(called - declared - own)
+    helpers_called = set(re.findall(r"\b(Vsr[A-Z][A-Za-z0-9]+)\s*\(", text))
+    helpers_defined = set(re.findall(r"^(Vsr[A-Z][A-Za-z0-9]+)\s*\(", text, flags=re.M))
+    assert helpers_called <= helpers_defined, sorted(helpers_called - helpers_defined)

@@ -9,8 +9,9 @@
 // Mapping (wave64): LPR lanes share one corpus row, each lane owning C float4 chunks of it, so one
 // wave load instruction reads 64/LPR rows as contiguous LPR*16-byte segments (1 KiB per instruction,
 // fully coalesced).  A wave iteration covers a tile of RW = R * 64/LPR rows with R*C independent
-// 16-byte loads in flight per lane, and the NEXT tile's loads are issued before the current tile is
-// computed.  Up to `qmax` queries share the pass: their vectors sit in LDS and are applied to the
+// 16-byte loads in flight per lane (several waves per SIMD overlap one tile's loads with another's
+// arithmetic; issuing the next tile's loads early -- VSR_PREFETCH -- is compiled out: it costs the
+// registers that occupancy needs).  Up to `qmax` queries share the pass: their vectors sit in LDS and are applied to the
 // register-resident tile in sub-batches of QI, so one HBM read serves all of them.  Per-row partial
 // sums are combined with a halving butterfly (R registers over LPR lanes), after which lane
 // (l % D == 0) owns the finished value of row slot l / D.
