@@ -247,7 +247,8 @@ inline size_t mfmaw_lds_bytes(bool int8 = false)
 constexpr uint32_t GQ_CAP = 16384;                      // candidate keys per query (a filter this small needs no threshold at all)
 constexpr uint32_t GQ_SAMPLE_CAP = 4096;                // sampled minima per query kept for the threshold seed (more: dropped)
 constexpr uint32_t GQ_MAX_KP = 512;                     // screening survivors the fused select + re-rank handles
-inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 48; }   // d = 61 .. 192; longer rows: K2
+inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 256; }  // d = 61 .. 1024 (more than 3 stages:
+                                                                                              // runtime stage loop); longer rows: K2
 inline int  mfmaw_qmax(uint32_t stride4) { (void) stride4; return 64; }
 hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
 // Screening planes: element x = hi + mid + e with hi = bf16(x), mid = bf16(x - hi) (|e| <= 2^-18 |x|).  A plane row holds,

@@ -66,7 +66,7 @@ constexpr int MW_RING = 8;                 // row-mapping ring (tiles): >= DEPTH
 #ifndef VSR_ABLATE
 #define VSR_ABLATE 0
 #endif
-constexpr int mw_depth(int nch) { return nch == 1 ? VSR_MW_DEPTH1 : nch == 2 ? 2 : 1; }
+constexpr int mw_depth(int nch) { return nch == 1 ? VSR_MW_DEPTH1 : nch == 2 ? 2 : 1; }   // (nch 0 = long rows: 1)
 // (a deeper register ring for the sample pass -- all of a workgroup's few tiles in flight at once -- was measured: the
 // occupancy it costs outweighs it: 72 -> 115 us)
 constexpr int mw_sample_depth(int nch, int pl) { (void) pl; return mw_depth(nch); }
@@ -97,9 +97,15 @@ template <int METRIC, int NCH, bool SAMPLE, int PL, int DEPTH, int EPI = 0>
 __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide_kernel(const ScanParams p)
 {
     constexpr bool HO = PL == 1, I8 = PL == 2;
+    // NCH == 0: LONG rows (more than 3 stages, d > 192): the stage count is a runtime value, ONE stage of rows and of B
+    // fragments is in registers at a time, and the next stage's rows and fragments (the query planes sit in L2: 3 KB
+    // per query at d = 768) are in flight under the current stage's MFMAs
+    constexpr bool LONG = NCH == 0;
+    constexpr int NCHR = LONG ? 1 : NCH;                                       // stages held in registers
     constexpr int SR = I8 ? 8 : MW_S;                                          // 16-byte chunks per row and stage
     constexpr int NU = I8 ? 2 : 4;                                             // chunks a thread stages per tile and stage
     static_assert(!I8 || (NCH == 1 && METRIC == M_L2), "int8 planes: one stage (d <= 128), L2 only");
+    static_assert(!LONG || DEPTH == 1, "long rows: one stage ahead");
     static_assert(DEPTH >= 1 && DEPTH <= 4 && DEPTH + 2 <= MW_RING, "row-mapping ring too short");
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
     const int kq = lane >> 4;
     const int jq = li;
     constexpr int NBLK = I8 ? 2 : HO ? 4 : 2;                                  // K-blocks per stage (32 bf16 or 64 int8 each)
-    bf16x8 bh[NCH][NBLK], bm[NCH][NBLK];                                        // B fragments: hi / mid planes of the query
+    bf16x8 bh[NCHR][NBLK], bm[NCHR][NBLK];                                      // B fragments: hi / mid planes of the query
+    const uint4* my_qsrc = nullptr;                                            // LONG: where this lane's fragments come from
     i32x4 b8[NBLK];                                                            // ... or its int8 plane
     const uint32_t my_qi = g0 * MF_NQ + (uint32_t) jq < (uint32_t) MW_NQ ? g0 * MF_NQ + (uint32_t) jq : 0u;
     float my_qn;
@@ -166,12 +173,13 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
         my_qn = p.q_norm2[slot];
         // query planes: per stage [hi chunks | mid chunks] (8 + 8 of a 64-float stage; 16 + 16 of a 128-float one)
         const uint4* qsrc = p.q_scr + (size_t) slot * (HO ? 2 * pstride4 : pstride4);
+        my_qsrc = qsrc;
         if constexpr (I8) {
 #pragma unroll
             for (int blk = 0; blk < NBLK; ++blk) b8[blk] = __builtin_bit_cast(i32x4, qsrc[blk * 4 + kq]);
         } else {
 #pragma unroll
-            for (int s = 0; s < NCH; ++s)
+            for (int s = 0; s < NCHR; ++s)
 #pragma unroll
                 for (int blk = 0; blk < NBLK; ++blk) {
                     bh[s][blk] = __builtin_bit_cast(bf16x8, qsrc[s * (HO ? 32 : 16) + blk * 4 + kq]);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
     // ---- staging: thread -> (row slot u * 16 + lrow, chunk lchunk) of every stage ----
     const int lrow = I8 ? tid >> 3 : tid >> 4, lchunk = I8 ? tid & 7 : tid & 15;
     constexpr int LROWS = I8 ? 32 : 16;                            // row slots one staging step of the workgroup covers
-    uint4 X[DEPTH][NCH][NU];
+    uint4 X[DEPTH][NCHR][NU];
     const uint32_t last_row = p.n_rows - 1u;
     auto issue = [&](auto dc, auto sc, uint32_t it_) {             // loads of tile it_, stage S into ring slot D (no waits)
         // An invalid slot (masked row, ragged tile) loads row 0 and its products are discarded by the epilogue's row
@@ -283,7 +291,30 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
             X[D][S][u] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
+    const uint32_t nch_rt = LONG ? pstride4 / (uint32_t) SR : (uint32_t) NCH;     // stages per row
+    auto issue_rt = [&](uint32_t it_, uint32_t s_) {               // LONG: the rows of (tile it_, stage s_) into X[0][0]
+        const uint32_t chunk = s_ * (uint32_t) SR + (uint32_t) lchunk;
+        const int32_t* ridx = rowidx + (it_ % MW_RING) * 64;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int32_t r = ridx[u * LROWS + lrow];
+            const uint32_t rc = (uint32_t) (r < 0 ? 0 : r);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(p.scr + (size_t) (rc < last_row ? rc : last_row) * pstride4 + chunk);
+            X[0][0][u] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto load_b = [&](uint32_t s_, bf16x8 (&h)[NBLK], bf16x8 (&m)[NBLK]) {    // LONG: B fragments of stage s_
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            h[blk] = __builtin_bit_cast(bf16x8, my_qsrc[s_ * (HO ? 32u : 16u) + (uint32_t) (blk * 4 + kq)]);
+            m[blk] = __builtin_bit_cast(bf16x8, my_qsrc[s_ * (HO ? 32u : 16u) + (HO ? 16u : 8u) + (uint32_t) (blk * 4 + kq)]);
+        }
+    };
     auto issue_tile = [&](auto dc, uint32_t it_) {
+        if constexpr (LONG) {
+            issue_rt(it_, 0u);
+            return;
+        }
         issue(dc, std::integral_constant<int, 0>{}, it_);
         if constexpr (NCH > 1) issue(dc, std::integral_constant<int, 1>{}, it_);
         if constexpr (NCH > 2) issue(dc, std::integral_constant<int, 2>{}, it_);
@@ -445,9 +476,71 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                 }
                 buf ^= 1;
             };
-            do_stage(std::integral_constant<int, 0>{});
-            if constexpr (NCH > 1) do_stage(std::integral_constant<int, 1>{});
-            if constexpr (NCH > 2) do_stage(std::integral_constant<int, 2>{});
+            if constexpr (LONG) {
+                for (uint32_t s = 0; s < nch_rt; ++s) {
+                    uint4* img = stage + (size_t) buf * (MW_ROWS * SR);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int slot = u * LROWS + lrow;
+                        img[slot * SR + (lchunk ^ (slot & (SR - 1)))] = X[0][0][u];
+                    }
+                    {
+                        // row mapping of the tiles ahead: the loads run at EVERY stage (a load inside a conditional block
+                        // would cost the counted waits; these hit the caches), their results are committed at stage 0
+                        int32_t r2;
+                        uint64_t b2;
+                        float n2;
+                        start_rows(dsc_a[0], r2, b2, n2);
+                        const uint2 d2 = fetch_desc(it + 3);
+                        if (s == 0) {
+                            if (f_n) flush_store();
+                            finish_rows(it + 1, pend_row[0], pend_bw[0], pend_nrm[0]);
+                            pend_row[0] = r2;
+                            pend_bw[0] = b2;
+                            pend_nrm[0] = n2;
+                            dsc_a[0] = d2;
+                        }
+                    }
+                    lds_barrier();
+                    if (s == 0 && !f_n && p_tail - p_head >= 64u * FL_R) flush_issue();
+                    const bool last = s + 1 == nch_rt;
+                    issue_rt(last ? it + 1 : it, last ? 0u : s + 1);       // next stage's rows ...
+                    bf16x8 nh[NBLK], nm[NBLK];
+                    load_b(last ? 0u : s + 1, nh, nm);                     // ... and B fragments, under this stage's MFMAs
+                    if (gact) {
+#pragma unroll
+                        for (int h0 = 0; h0 < NS; h0 += NH)
+#pragma unroll
+                            for (int blk = 0; blk < NBLK; ++blk) {
+                                bf16x8 ah[NH], am[NH];
+#pragma unroll
+                                for (int i = 0; i < NH; ++i) {
+                                    const int row = ((int) sub0 + h0 + i) * 16 + li;
+                                    ah[i] = __builtin_bit_cast(bf16x8, img[row * MW_S + ((blk * 4 + kq) ^ li)]);
+                                    if constexpr (!HO) am[i] = __builtin_bit_cast(bf16x8, img[row * MW_S + ((8 + blk * 4 + kq) ^ li)]);
+                                }
+#pragma unroll
+                                for (int i = 0; i < NH; ++i) acc[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[0][blk], acc[h0 + i], 0, 0, 0);
+#pragma unroll
+                                for (int i = 0; i < NH; ++i) acc[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm[0][blk], acc[h0 + i], 0, 0, 0);
+                                if constexpr (!HO) {
+#pragma unroll
+                                    for (int i = 0; i < NH; ++i) acc[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh[0][blk], acc[h0 + i], 0, 0, 0);
+                                }
+                            }
+                    }
+#pragma unroll
+                    for (int blk = 0; blk < NBLK; ++blk) {
+                        bh[0][blk] = nh[blk];
+                        bm[0][blk] = nm[blk];
+                    }
+                    buf ^= 1;
+                }
+            } else {
+                do_stage(std::integral_constant<int, 0>{});
+                if constexpr (NCH > 1) do_stage(std::integral_constant<int, 1>{});
+                if constexpr (NCH > 2) do_stage(std::integral_constant<int, 2>{});
+            }
             if constexpr (I8) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
@@ -629,11 +722,17 @@ hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream
         return sample ? launch(mfma_wide_kernel<METRIC, N, true, 0, mw_sample_depth(N, 0)>)
                       : few ? launch(mfma_wide_kernel<METRIC, N, false, 0, D, METRIC == M_L2 ? 1 : 0>) : launch(mfma_wide_kernel<METRIC, N, false, 0, D>);
     };
+    if (nch > 3 || (p.plane_ho == 1 && nch > 2)) {                            // long rows: runtime stage count (NCH = 0)
+        if (p.plane_ho == 2) return hipErrorInvalidValue;
+        if (p.plane_ho) return sample ? launch(mfma_wide_kernel<METRIC, 0, true, 1, 1>) : launch(mfma_wide_kernel<METRIC, 0, false, 1, 1>);
+        return sample ? launch(mfma_wide_kernel<METRIC, 0, true, 0, 1>) : launch(mfma_wide_kernel<METRIC, 0, false, 0, 1>);
+    }
     switch (nch) {
+    case 0: return hipErrorInvalidValue;
     case 1: return pick(std::integral_constant<int, 1>{});
     case 2: return pick(std::integral_constant<int, 2>{});
     case 3: return pick(std::integral_constant<int, 3>{});
-    default: return hipErrorInvalidValue;                                     // longer rows: K2 (vsr_mfma.h)
+    default: return hipErrorInvalidValue;
     }
 }
 
