@@ -379,6 +379,8 @@ def main():
             else:
                 for key in ("scan_launches", "scan_ms", "scan_bytes", "scan_rows", "scan_pairs", "unique_rows"):
                     st[key] = [a + b for a, b in zip(st[key], one[key])]
+                for key in ("host_ms", "host_wait_ms"):
+                    st[key] += one[key]
         sim_ok = None
         if sim_world > 1:      # development check of the overlapped choreography on one GPU: merged == local
             lb = (state["i"] - 1) % nbuf                 # the last batch: slot lb % G of the last group record
@@ -471,8 +473,13 @@ def main():
         except (OSError, ValueError, KeyError, IndexError):
             pass
         roof["workload_tag"] = tag
+        wait_ms = r["stats"]["host_wait_ms"] / args.steps
         return {"value": round(nq * args.steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
-                "host_enqueue_ms_per_step": round(r["t_enq"] / args.steps * 1e3, 4), "roofline": roof,
+                "host_enqueue_ms_per_step": round(r["t_enq"] / args.steps * 1e3, 4),
+                # ... of which the host only WAITED for the GPU (staging block of an earlier batch still in use): the rest is
+                # the work the host does per step (bench loop + planner + launches)
+                "host_busy_ms_per_step": round(r["t_enq"] / args.steps * 1e3 - wait_ms, 4),
+                "host_library_ms_per_step": round(r["stats"]["host_ms"] / args.steps - wait_ms, 4), "roofline": roof,
                 "screening_flagged_queries": int(r["flagged"])}
 
     recs = {leg: leg_record(leg, r) for leg, r in results.items()}
@@ -490,6 +497,8 @@ def main():
         "roofline": main_rec["roofline"],
         "setup_s": {"generate": round(t_gen, 1), "load": round(t_load, 1)},
         "host_enqueue_ms_per_step": main_rec["host_enqueue_ms_per_step"],
+        "host_busy_ms_per_step": main_rec["host_busy_ms_per_step"],
+        "host_library_ms_per_step": main_rec["host_library_ms_per_step"],
         "screening_flagged_queries": main_rec["screening_flagged_queries"],
     }
     for leg in legs[1:]:

@@ -254,6 +254,10 @@ typedef struct {
     int64_t scan_pairs[2];      /* (row, query) pairs = sum over passes of rows * queries: flops = 2 * dim * pairs       */
     int64_t unique_rows[2];     /* rows read at least once per launch, summed over launches: distinct filter parts'
                                    rows, capped at the corpus size (exact when the parts are disjoint, e.g. classes)  */
+    /* host side of the search entry points (always on): time spent inside them, and the part of it spent WAITING for
+       the previous batch's staging block (back-pressure from the GPU, not work) */
+    double  host_ms;
+    double  host_wait_ms;
 } vsr_stats;
 
 int vsr_profiling(vsr_ctx* ctx, int enable);      /* HIP events on the launch stream: 1 = around every launch class (scan, sample, K5), 2 = around the main scan launch only, 0 = off */

@@ -1529,7 +1529,11 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         const auto w0 = std::chrono::steady_clock::now();
         HIPCHK(hipEventSynchronize(ctx->desc_done));
         ctx->desc_pending = false;
-        ctx->host_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+        {
+            const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+            ctx->host_us[1] += waited;
+            ctx->stats.host_wait_ms += waited * 1e-3;
+        }
     }
     if ((rc = ctx->h_desc.reserve(h_total))) return rc;
     if ((rc = ctx->d_desc.reserve(total))) return rc;
@@ -1743,7 +1747,9 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         std::chrono::steady_clock::time_point t0;
         ~HostTimer()
         {
-            ctx->host_us[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            const double spent = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            ctx->host_us[2] += spent;
+            ctx->stats.host_ms += spent * 1e-3;
             ctx->host_calls++;
         }
     } host_timer{ctx, h0};
@@ -1887,7 +1893,11 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         const auto w0 = std::chrono::steady_clock::now();
         HIPCHK(hipEventSynchronize(ctx->desc_done));
         ctx->desc_pending = false;
-        ctx->host_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+        {
+            const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+            ctx->host_us[1] += waited;
+            ctx->stats.host_wait_ms += waited * 1e-3;
+        }
     }
     if ((rc = ctx->h_desc.reserve(total))) return rc;
     if ((rc = ctx->d_desc.reserve(total))) return rc;

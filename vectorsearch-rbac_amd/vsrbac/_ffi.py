@@ -19,7 +19,8 @@ class Stats(C.Structure):
     _fields_ = [("scan_launches", C.c_int64 * 2), ("scan_ms", C.c_double * 2), ("scan_bytes", C.c_int64 * 2),
                 ("scan_rows", C.c_int64 * 2), ("select_launches", C.c_int64), ("select_ms", C.c_double),
                 ("queries", C.c_int64), ("search_ms", C.c_double),
-                ("scan_pairs", C.c_int64 * 2), ("unique_rows", C.c_int64 * 2)]
+                ("scan_pairs", C.c_int64 * 2), ("unique_rows", C.c_int64 * 2),
+                ("host_ms", C.c_double), ("host_wait_ms", C.c_double)]
 
 
 # every symbol include/vsrbac.h declares: name -> (restype, argtypes)
