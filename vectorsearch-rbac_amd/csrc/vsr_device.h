@@ -249,7 +249,9 @@ constexpr uint32_t GQ_SAMPLE_CAP = 4096;                // sampled minima per qu
 constexpr uint32_t GQ_MAX_KP = 512;                     // screening survivors the fused select + re-rank handles
 inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 <= 256; }  // d = 61 .. 1024 (more than 3 stages:
                                                                                               // runtime stage loop); longer rows: K2
-inline int  mfmaw_qmax(uint32_t stride4) { (void) stride4; return 64; }
+// queries per pass: 64 (one 16-query group per wave); long rows (hi + mid planes of more than 3 stages, hi-only of more than
+// 2): 128, two groups per wave
+inline int  mfmaw_qmax(uint32_t pstride4, bool ho) { return pstride4 / 16 > (ho ? 2u : 3u) ? 128 : 64; }
 hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
 // Screening planes: element x = hi + mid + e with hi = bf16(x), mid = bf16(x - hi) (|e| <= 2^-18 |x|).  A plane row holds,
 // for every 64-float stage s, 8 chunks of 8 hi values followed by 8 chunks of 8 mid values (16 bytes each, zero padded):

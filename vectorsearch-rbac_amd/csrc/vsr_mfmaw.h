@@ -73,10 +73,13 @@ constexpr int mw_sample_depth(int nch, int pl) { (void) pl; return mw_depth(nch)
 #ifndef VSR_MW_OCC8
 #define VSR_MW_OCC8 4
 #endif
+#ifndef VSR_MW_OCCL
+#define VSR_MW_OCCL 2            // long rows: two query groups per wave
+#endif
 constexpr int mw_occ(int nch, int pl = 0, bool sample = false)
 {
     (void) sample;
-    return pl == 2 ? VSR_MW_OCC8 : nch == 1 ? VSR_MW_OCC1 : 2;
+    return pl == 2 ? VSR_MW_OCC8 : nch == 1 ? VSR_MW_OCC1 : nch == 0 ? VSR_MW_OCCL : 2;
 }   // int8: 32 KB of LDS, ~120 VGPRs
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases global memory, and since gfx950 counts
@@ -93,7 +96,7 @@ __device__ __forceinline__ void lds_barrier()
 // PL: plane kind of the corpus (ScanParams::plane_ho): 0 = bf16 hi + mid, 1 = bf16 hi only, 2 = int8 (u8-exact corpus and
 // queries, elements stored as x - 128; L2 only: |x' - q'|^2 = |x - q|^2, exact in int32 / fp32; 128 bytes per row, the
 // tile image has 8 chunks per row and v_mfma_i32_16x16x64_i8 covers d = 128 in two instructions).
-template <int METRIC, int NCH, bool SAMPLE, int PL, int DEPTH, int EPI = 0>
+template <int METRIC, int NCH, bool SAMPLE, int PL, int DEPTH, int EPI = 0, int NGT = 1>
 __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide_kernel(const ScanParams p)
 {
     constexpr bool HO = PL == 1, I8 = PL == 2;
@@ -199,8 +202,31 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
     const bool open = my_tau == KEY_EMPTY;
     // screening limit: a value passes unless it is greater (NaN values pass; an open threshold admits everything)
     const float tau_lim = open ? __builtin_inff() : mono_to_float((uint32_t) (my_tau >> 32));
-    uint64_t* my_cand = p.qcand + (size_t) my_slot * p.capq;
-    uint32_t* my_cnt = p.qcnt + my_slot;
+    // LONG rows: a pass holds up to 128 queries and wave w also owns query group w + 4 (the same A fragments feed both
+    // groups' MFMAs: half the passes over the rows).  Its lanes carry a second set of per-query state.
+    constexpr int NG = NGT;                                                    // query groups per wave (2: LONG only)
+    static_assert(NG == 1 || LONG, "two query groups per wave: long rows only");
+    const uint32_t g1 = (uint32_t) wave + 4u;
+    const bool gact2 = NG == 2 && rsplit == 1u && g1 < ngt;                    // wave-uniform
+    const uint32_t my_qi2 = g1 * MF_NQ + (uint32_t) jq;
+    const bool qok2 = gact2 && my_qi2 < q_count;
+    uint32_t my_slot2 = my_slot;
+    float my_qn2 = 0.0f, tau_lim2 = -__builtin_inff();
+    const uint4* my_qsrc2 = nullptr;
+    bf16x8 bh2[NBLK], bm2[NBLK];                                               // group B's fragments of the current stage
+    if constexpr (NG == 2) {
+        my_slot2 = p.q_slots[grp.q_begin + (qok2 ? my_qi2 : 0u)];
+        const uint64_t t2 = p.tau_init ? p.tau_init[my_slot2] : KEY_EMPTY;
+        tau_lim2 = t2 == KEY_EMPTY ? __builtin_inff() : mono_to_float((uint32_t) (t2 >> 32));
+        my_qn2 = p.q_norm2[my_slot2];
+        my_qsrc2 = p.q_scr + (size_t) my_slot2 * (HO ? 2 * pstride4 : pstride4);
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            bh2[blk] = __builtin_bit_cast(bf16x8, my_qsrc2[blk * 4 + kq]);
+            bm2[blk] = __builtin_bit_cast(bf16x8, my_qsrc2[(HO ? 16 : 8) + blk * 4 + kq]);
+        }
+    }
+    const uint32_t col_slot = lane < MF_NQ ? my_slot : my_slot2;               // lane c < 16 * NG owns candidate column c
 
     // ---- row mapping pipeline (wave 0, lane = row slot): at tile `it` the descriptor of tile it+3*DEPTH is fetched, the
     // row / bitmap word / norm of tile it+2*DEPTH are started and those of tile it+DEPTH are written to the LDS ring, where
@@ -340,7 +366,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
     uint32_t f_base = 0;                                           // lanes 0..15: first position of column `lane`
 #pragma unroll
     for (int r = 0; r < FL_R; ++r) f_rank[r] = 0;
-    auto flush_issue = [&]() {                                     // phase A
+    auto flush_issue = [&]() __attribute__((always_inline)) {      // phase A
         const uint32_t have = p_tail - p_head;
         f_n = have < 64u * FL_R ? have : 64u * FL_R;
         uint32_t col[FL_R];
@@ -351,7 +377,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
         }
         uint32_t mine = 0;
 #pragma unroll
-        for (int c = 0; c < MF_NQ; ++c) {
+        for (int c = 0; c < MF_NQ * NG; ++c) {
             uint32_t before = 0;
 #pragma unroll
             for (int r = 0; r < FL_R; ++r) {
@@ -362,16 +388,17 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
             }
             if (lane == c) mine = before;
         }
-        if (lane < MF_NQ && mine) f_base = atomicAdd(my_cnt, mine);            // lane c < 16 is (kq 0, column c): its own query
+        if (lane < MF_NQ * NG && mine) f_base = atomicAdd(p.qcnt + col_slot, mine);   // lane c owns column c: (kq 0, group A's
+                                                                                      // column c) or (kq 1, group B's c - 16)
     };
-    auto flush_store = [&]() {                                     // phase B
+    auto flush_store = [&]() __attribute__((always_inline)) {      // phase B
 #pragma unroll
         for (int r = 0; r < FL_R; ++r) {
             const uint32_t e = (uint32_t) (r * 64 + lane);
             const uint32_t idx = (p_head + e) % MW_PEND;
             const uint32_t c = e < f_n ? pend_c[idx] : 0u;
             const uint32_t base = (uint32_t) __shfl((int) f_base, (int) c);
-            const uint32_t slot = (uint32_t) __shfl((int) my_slot, (int) c);
+            const uint32_t slot = (uint32_t) __shfl((int) col_slot, (int) c);
             if (e < f_n) {
                 const uint32_t row = pend_r[idx];
                 const uint32_t at = base + f_rank[r];
@@ -383,7 +410,12 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
         f_n = 0;
     };
     // one entry per lane with `has` (wave-uniform call): the position is the wave's running count + the lane's rank
-    auto park_mask = [&](uint64_t act, bool has, uint32_t key_hi, uint32_t row) {
+    auto park_mask = [&](uint64_t act, bool has, uint32_t key_hi, uint32_t row, uint32_t col = 0xFFFFFFFFu, uint32_t slot_ = 0u)
+                         __attribute__((always_inline)) {
+        if (col == 0xFFFFFFFFu) {                                  // group A: the lane's own column and query
+            col = (uint32_t) jq;
+            slot_ = my_slot;
+        }
         const uint32_t room = MW_PEND - (p_tail - p_head);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) act, 0u));
         if (has) {
@@ -391,16 +423,19 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                 const uint32_t at = (p_tail + rank) % MW_PEND;
                 pend_v[at] = key_hi;
                 pend_r[at] = row;
-                pend_c[at] = (uint32_t) jq;
+                pend_c[at] = col;
             } else {                                               // the ring is full (a burst): reserve directly
-                const uint32_t ga = atomicAdd(my_cnt, 1u);
-                if (ga < p.capq) my_cand[ga] = ((uint64_t) key_hi << 32) | (g_rank ? g_rank[row] : row);
+                const uint32_t ga = atomicAdd(p.qcnt + slot_, 1u);
+                if (ga < p.capq) p.qcand[(size_t) slot_ * p.capq + ga] = ((uint64_t) key_hi << 32) | (g_rank ? g_rank[row] : row);
             }
         }
         const uint32_t n_act = (uint32_t) __popcll(act);
         p_tail += n_act < room ? n_act : room;
     };
-    auto park = [&](bool has, uint32_t key_hi, uint32_t row) { park_mask(__ballot(has), has, key_hi, row); };
+    auto park = [&](bool has, uint32_t key_hi, uint32_t row, uint32_t col = 0xFFFFFFFFu, uint32_t slot_ = 0u)
+                    __attribute__((always_inline)) {
+        park_mask(__ballot(has), has, key_hi, row, col, slot_);
+    };
 
     auto run = [&](auto nsc) {
         constexpr int NS = decltype(nsc)::value;                   // 16-row sub-tiles of this wave (1, 2 or 4)
@@ -409,10 +444,12 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
         auto tile = [&](auto dc, uint32_t it) {
             constexpr int D = decltype(dc)::value;
             f32x4 acc[NS];
+            f32x4 acc2[NS];                                        // LONG: the wave's second query group
             i32x4 acc8[NS];                                        // int8 planes: exact integer dot products
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc8[i] = i32x4{0, 0, 0, 0};
             }
 
@@ -505,8 +542,16 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                     if (s == 0 && !f_n && p_tail - p_head >= 64u * FL_R) flush_issue();
                     const bool last = s + 1 == nch_rt;
                     issue_rt(last ? it + 1 : it, last ? 0u : s + 1);       // next stage's rows ...
-                    bf16x8 nh[NBLK], nm[NBLK];
+                    bf16x8 nh[NBLK], nm[NBLK], nh2[NBLK], nm2[NBLK];
                     load_b(last ? 0u : s + 1, nh, nm);                     // ... and B fragments, under this stage's MFMAs
+                    if constexpr (NG == 2) {
+                        const uint32_t sn = last ? 0u : s + 1;
+#pragma unroll
+                        for (int blk = 0; blk < NBLK; ++blk) {
+                            nh2[blk] = __builtin_bit_cast(bf16x8, my_qsrc2[sn * (HO ? 32u : 16u) + (uint32_t) (blk * 4 + kq)]);
+                            nm2[blk] = __builtin_bit_cast(bf16x8, my_qsrc2[sn * (HO ? 32u : 16u) + (HO ? 16u : 8u) + (uint32_t) (blk * 4 + kq)]);
+                        }
+                    }
                     if (gact) {
 #pragma unroll
                         for (int h0 = 0; h0 < NS; h0 += NH)
@@ -527,12 +572,26 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
 #pragma unroll
                                     for (int i = 0; i < NH; ++i) acc[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh[0][blk], acc[h0 + i], 0, 0, 0);
                                 }
+                                if constexpr (NG == 2) if (gact2) {   // the same A fragments against the second group
+#pragma unroll
+                                    for (int i = 0; i < NH; ++i) acc2[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh2[blk], acc2[h0 + i], 0, 0, 0);
+#pragma unroll
+                                    for (int i = 0; i < NH; ++i) acc2[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm2[blk], acc2[h0 + i], 0, 0, 0);
+                                    if constexpr (!HO) {
+#pragma unroll
+                                        for (int i = 0; i < NH; ++i) acc2[h0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh2[blk], acc2[h0 + i], 0, 0, 0);
+                                    }
+                                }
                             }
                     }
 #pragma unroll
                     for (int blk = 0; blk < NBLK; ++blk) {
                         bh[0][blk] = nh[blk];
                         bm[0][blk] = nm[blk];
+                        if constexpr (NG == 2) {
+                            bh2[blk] = nh2[blk];
+                            bm2[blk] = nm2[blk];
+                        }
                     }
                     buf ^= 1;
                 }
@@ -590,7 +649,9 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                             }
                     }
                 }
-            } else if (gact) {
+            } else {
+              auto epi = [&](const f32x4 (&acc)[NS], float my_qn, float tau_lim, bool qok, uint32_t col, uint32_t eslot)
+                             __attribute__((always_inline)) {
                 const int32_t* ridx = rowidx + (it % MW_RING) * 64;
                 const float* rnrm = rownorm + (it % MW_RING) * 64;
                 uint32_t pmask = 0;
@@ -633,7 +694,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                             best = o < best ? o : best;
                             if (kq != 0) best = KEY_EMPTY;
                         }
-                        park(best != KEY_EMPTY, (uint32_t) (best >> 32), (uint32_t) best);
+                        park(best != KEY_EMPTY, (uint32_t) (best >> 32), (uint32_t) best, col, eslot);
                     } else {
                         // one round per survivor of the busiest lane (1 - 2 at the usual ~1 % admission) instead of a
                         // predicated body per result register: the parking position is the wave's running count (wave
@@ -661,10 +722,15 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                                 }
                             }
                             const float v = screen_value<METRIC>(a, rnrm[slot], my_qn);
-                            park(has, mono_bits(v), (uint32_t) ridx[slot]);
+                            park(has, mono_bits(v), (uint32_t) ridx[slot], col, eslot);
                         }
                     }
                 }
+              };
+              if (gact) epi(acc, my_qn, tau_lim, qok, (uint32_t) jq, my_slot);
+              if constexpr (NG == 2) {
+                  if (gact2) epi(acc2, my_qn2, tau_lim2, qok2, (uint32_t) (MF_NQ + jq), my_slot2);
+              }
             }
         };
         // the loop body is branch-free around its loads and exactly periodic (the tile count is padded to a multiple of
@@ -724,6 +790,10 @@ hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream
     };
     if (nch > 3 || (p.plane_ho == 1 && nch > 2)) {                            // long rows: runtime stage count (NCH = 0)
         if (p.plane_ho == 2) return hipErrorInvalidValue;
+        if (p.qmax > 64) {                                                     // passes of up to 128 queries: two groups per wave
+            if (p.plane_ho) return sample ? launch(mfma_wide_kernel<METRIC, 0, true, 1, 1, 0, 2>) : launch(mfma_wide_kernel<METRIC, 0, false, 1, 1, 0, 2>);
+            return sample ? launch(mfma_wide_kernel<METRIC, 0, true, 0, 1, 0, 2>) : launch(mfma_wide_kernel<METRIC, 0, false, 0, 1, 0, 2>);
+        }
         if (p.plane_ho) return sample ? launch(mfma_wide_kernel<METRIC, 0, true, 1, 1>) : launch(mfma_wide_kernel<METRIC, 0, false, 1, 1>);
         return sample ? launch(mfma_wide_kernel<METRIC, 0, true, 0, 1>) : launch(mfma_wide_kernel<METRIC, 0, false, 0, 1>);
     }

@@ -1166,7 +1166,21 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     const bool k2w_ok = k2_any && allow_wide && c->d_scr && keep <= GQ_MAX_KP && !ctx->no_wide && ctx->seeding;
     const bool k2_ok = k2w_ok || (k2_any && mfma_cap_for_k(keep) <= 8192 && mfma_lds_bytes(c->stride4) <= 150 * 1024);
     int qmax;
-    if (k2w_ok) qmax = ctx->max_qb_set ? std::min(ctx->max_qb, mfmaw_qmax(c->stride4)) : mfmaw_qmax(c->stride4);
+    int wq = mfmaw_qmax(c->pstride4, !c->scr_has_mid);
+    if (wq > 64) {
+        // long rows: 128-query passes (two groups per wave: a heavier kernel that also fetches the second group's fragments
+        // where a pass has none) pay when nearly all (part, query) items sit in parts seen by more than 64 queries --
+        // unfiltered batches: 1M x 768 x 1000 queries 9.9 -> 7.9 ms; a role mix (1000 users over 100 roles) would lose:
+        // 1.10 -> 1.39 ms
+        uint64_t big = 0, all = 0;
+        for (size_t g = 0; g < gcount.size(); ++g) {
+            const uint32_t cnt = gcount[g] - (g ? gcount[g - 1] : 0u);         // gcount holds end offsets after the scatter
+            all += cnt;
+            if (cnt > 64) big += cnt;
+        }
+        if (big * 10 < all * 9) wq = 64;
+    }
+    if (k2w_ok) qmax = ctx->max_qb_set ? std::min(ctx->max_qb, wq) : wq;
     else if (k2_ok) qmax = std::min(ctx->max_qb_set ? ctx->max_qb : 16, mfma_qmax(c->stride4));
     else qmax = std::min(ctx->max_qb_set ? ctx->max_qb : 16, mq_ok ? mq_qmax(c->dim) : scan_qmax(c->dim, k));
     if (k2_ok && !k2w_ok && !ctx->max_qb_set && qmax >= 16 && c->stride4 > 64) {
@@ -1224,7 +1238,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     plan.k2w = plan.k2 && k2w_ok;
     plan.mq = plan.qi == 4 && mq_ok && !plan.k2;
     plan.keep = plan.k2 ? keep : (uint32_t) k;
-    if (plan.k2w) plan.qmax = 64;                           // query slots per workgroup: one 16-query group per wave
+    if (plan.k2w) plan.qmax = (uint32_t) wq;                // query slots per workgroup: one (long rows: two) 16-query groups per wave
     else if (plan.k2) plan.qmax = plan.qmax > 16 ? 32 : 16;
     plan.int8 = plan.k2w && c->d_scr8 && metric == VSR_METRIC_L2 && ctx->int8_this_call;
     if (plan.int8) plan.keep = (uint32_t) std::max(k, 32);  // exact screening: no second half of survivors to re-rank
