@@ -69,6 +69,9 @@ constexpr int MW_RING = 8;                 // row-mapping ring (tiles): >= DEPTH
 constexpr int mw_depth(int nch) { return nch == 1 ? VSR_MW_DEPTH1 : nch == 2 ? 2 : 1; }   // (nch 0 = long rows: 1)
 // (a deeper register ring for the sample pass -- all of a workgroup's few tiles in flight at once -- was measured: the
 // occupancy it costs outweighs it: 72 -> 115 us)
+#ifndef VSR_MW_DEPTH8
+#define VSR_MW_DEPTH8 1          // int8 planes: tiles are 8 KB, so a deeper ring is cheap in registers (8 VGPRs per tile)
+#endif
 constexpr int mw_sample_depth(int nch, int pl) { (void) pl; return mw_depth(nch); }
 #ifndef VSR_MW_OCC8
 #define VSR_MW_OCC8 4
@@ -776,7 +779,8 @@ hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream
         if (p.plane_ho == 2) {
             if constexpr (N == 1 && METRIC == M_L2)                            // int8 planes: d <= 128, L2
                 return sample ? launch(mfma_wide_kernel<METRIC, 1, true, 2, mw_sample_depth(1, 2)>)
-                              : few ? launch(mfma_wide_kernel<METRIC, 1, false, 2, D, 1>) : launch(mfma_wide_kernel<METRIC, 1, false, 2, D>);
+                              : few ? launch(mfma_wide_kernel<METRIC, 1, false, 2, VSR_MW_DEPTH8, 1>)
+                                    : launch(mfma_wide_kernel<METRIC, 1, false, 2, VSR_MW_DEPTH8>);
             return hipErrorInvalidValue;
         }
         if (p.plane_ho) {
