@@ -1265,7 +1265,13 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
             seed_div = std::max<uint32_t>(seed_div, (uint32_t) (budget / (2 * cus)));
         }
     }
-    if (plan.k2w) seed_div = 1;                                   // the sample launch: the same workgroups, every ss-th tile
+    if (plan.k2w) {
+        // the sample launch visits every ss-th tile: a workgroup of it is all prologue and memory latency, so it gets ONE
+        // resident round of workgroups (each then walks ~12 tiles instead of three rounds walking 4: 72 -> ~45 us on the
+        // 10M-row corpus); launches that fit one round anyway (a shard) keep the main launch's workgroups
+        const int64_t slots = (plan.int8 ? 4 : 3) * cus;
+        seed_div = (uint32_t) std::max<int64_t>(1, (budget + slots - 1) / slots);
+    }
 
     // blocks per pass, then the partial lists of every query as CSR (count, prefix, fill): no per-query vectors
     static thread_local std::vector<uint32_t> loff, lcur, lids, lids_s;
