@@ -9,8 +9,9 @@ for r in rows:
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
     print(f"{k:72s} n={len(v):5d} avg={sum(v)/len(v):9.1f} us  min={min(v):8.1f}  total={sum(v)/1000:8.2f} ms")
 main = [i for i, r in enumerate(rows) if "wide_kernel" in r["Kernel_Name"] and "true" not in r["Kernel_Name"].split("(")[0].split(",")[2]]
-if len(main) >= 3:
-    a, b = main[-3], main[-2]
+if len(main) >= 6:
+    a, b = main[len(main) // 2], main[len(main) // 2 + 1]        # two consecutive batches from the middle of the timed loop
+if len(main) >= 6:
     seg = rows[a - 3:b + 4]
     t0 = int(seg[0]["Start_Timestamp"])
     prev_end = t0
