@@ -69,6 +69,9 @@ constexpr int MW_RING = 8;                 // row-mapping ring (tiles): >= DEPTH
 constexpr int mw_depth(int nch) { return nch == 1 ? VSR_MW_DEPTH1 : nch == 2 ? 2 : 1; }   // (nch 0 = long rows: 1)
 // (a deeper register ring for the sample pass -- all of a workgroup's few tiles in flight at once -- was measured: the
 // occupancy it costs outweighs it: 72 -> 115 us)
+#ifndef VSR_LONG_MAP_EVERY_STAGE
+#define VSR_LONG_MAP_EVERY_STAGE 1     // (0: mapping loads at stage 0 only -- measured: no faster, 8.2 vs 8.0 ms at 1M x 768)
+#endif
 #ifndef VSR_MW_DEPTH8
 #define VSR_MW_DEPTH8 1          // int8 planes: tiles are 8 KB, so a deeper ring is cheap in registers (8 VGPRs per tile)
 #endif
@@ -527,6 +530,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                     {
                         // row mapping of the tiles ahead: the loads run at EVERY stage (a load inside a conditional block
                         // would cost the counted waits; these hit the caches), their results are committed at stage 0
+#if VSR_LONG_MAP_EVERY_STAGE
                         int32_t r2;
                         uint64_t b2;
                         float n2;
@@ -540,6 +544,14 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                             pend_nrm[0] = n2;
                             dsc_a[0] = d2;
                         }
+#else
+                        if (s == 0) {
+                            if (f_n) flush_store();
+                            finish_rows(it + 1, pend_row[0], pend_bw[0], pend_nrm[0]);
+                            start_rows(dsc_a[0], pend_row[0], pend_bw[0], pend_nrm[0]);
+                            dsc_a[0] = fetch_desc(it + 3);
+                        }
+#endif
                     }
                     lds_barrier();
                     if (s == 0 && !f_n && p_tail - p_head >= 64u * FL_R) flush_issue();
