@@ -296,6 +296,8 @@ def main():
         state["i"] += 1
         overlap, n_sess = state["overlap"], state["n_sess"]
         b = i % nbuf                                             # slot b % G of group record b // G
+        if world > 1 and not overlap and not rehearsal:
+            b = i % G                                            # serial fall-back: group record 0 only
         qb = i % nb                                              # this step's query batch
         keys_b, blk_b, doc_b, dist_b = d_views[b]
         sess, st = sessions[i % n_sess], s_scan[i % n_sess]
@@ -316,9 +318,10 @@ def main():
             if state["open"] == G:
                 exchange_group(b // G, G)
                 state["open"] = 0
-        elif world > 1:                                           # plain loop (G = 1): scan, exchange, merge on one stream
+        elif world > 1:                                           # serial fall-back: scan, exchange, merge one after the other
+            torch.cuda.synchronize()                              # (the sessions' streams; no overlap wanted here)
             dist.all_gather_into_tensor(g_packs[0], d_packs[0])
-            ctx.merge_topk_packed_device(ptr(g_packs[0]), parts, nq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist),
+            ctx.merge_topk_packed_device(ptr(g_packs[0]), parts, gq, k, ptr(m_blk), ptr(m_doc), ptr(m_dist),
                                          ptr(m_keys), ptr(m_cnt))
 
     def barrier():
@@ -668,8 +671,9 @@ def main():
         qrow, quser = batches[qb]
         ranges = [[((d - 1) * 100, 100) for d in rbac.visible_docs(int(u)).astype(np.int64)] for u in quser[:m]]
         rows_o, dist_o, _ = orc.search_ranges("l2", xf, allvec[qb * nq:qb * nq + m], k, ranges, docf, blkf)
-        ok = bool((m_blk[:m].cpu().numpy() == blkf[rows_o]).all() and
-                  (m_dist[:m].cpu().numpy() == dist_o.astype(np.float32)).all())
+        off = (((state["i"] - 1) % nbuf) % G) * nq      # the last batch's slot of its group record
+        ok = bool((m_blk[off:off + m].cpu().numpy() == blkf[rows_o]).all() and
+                  (m_dist[off:off + m].cpu().numpy() == dist_o.astype(np.float32)).all())
         out["multi_rank_parity"] = {"queries": m, "ids_and_distances_identical": ok}
     if rank == 0:
         print(json.dumps(out), flush=True)
