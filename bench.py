@@ -181,6 +181,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    # development (N = 1 only, with VSR_BENCH_SIM_WORLD): a one-rank RCCL communicator, so that the simulated exchange
+    # goes through the real collective call on the exchange stream
+    nccl_one = world == 1 and os.environ.get("VSR_BENCH_NCCL_ONE") == "1"
+    if nccl_one:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29617")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     n, dim, k, nq = args.rows, args.dim, args.k, args.queries
     legs = [m for m in args.legs.split(",") if m]
     lo, hi = shard_bounds(n, world, rank, align=100)  # keep documents (100 rows) whole per shard
@@ -279,6 +286,8 @@ def main():
                 s_comm.wait_event(ev_scan[gb * G + j])
             if world > 1:
                 dist.all_gather_into_tensor(g_packs[gb], d_packs[gb])     # RCCL over xGMI: G * nq * k * 24 bytes per rank
+            elif nccl_one:      # development: the simulated exchange through a one-rank RCCL communicator (the real call path)
+                dist.all_gather_into_tensor(g_packs[gb][0:rec_g], d_packs[gb])
             else:
                 g_packs[gb][0:rec_g].copy_(d_packs[gb], non_blocking=True)
             ev_sent[gb].record(s_comm)
@@ -683,7 +692,7 @@ def main():
     for cx in sessions[1:]:
         cx.close()
     ctx.close()
-    if world > 1:
+    if world > 1 or nccl_one:
         dist.destroy_process_group()
 
 
