@@ -153,3 +153,27 @@ def test_gpu_cost_model_and_placement():
     import pytest
     with pytest.raises(ValueError):
         place_partitions(loads, heat, 2, mem_rows=10000)
+
+
+def test_bench_roofline_arithmetic():
+    """bench.py's roofline: unique rows priced in the layout the launched kernel reads (never more than HBM can deliver),
+    the fp32-equivalent beside it, and the MFMA floor at the peak of the products' type."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    k_i8 = "vsr::mfma_wide_kernel<L2, NCH=1, SAMPLE=false, PL=int8> (K2w, int8 planes)"
+    k_ho = "vsr::mfma_wide_kernel<L2, NCH=1, SAMPLE=false, HO=true> (K2w, bf16 hi-only planes)"
+    k_hm = "vsr::mfma_wide_kernel<COSINE, NCH=12, SAMPLE=false, HO=false> (K2w, bf16 hi+mid planes)"
+    k_k1 = "vsr::scan_kernel<L2, LPR=32, C=1, R=8, QI=1> (K1)"
+    assert bench.kernel_layout(k_i8, 128)[0] == 132 and bench.kernel_layout(k_ho, 128)[0] == 260
+    assert bench.kernel_layout(k_hm, 768)[0] == 768 * 4 + 4 and bench.kernel_layout(k_k1, 128)[0] == 512
+    st = {"scan_ms": [0.0, 4.0], "scan_launches": [0, 10], "scan_pairs": [0, 10 * 360_000_000], "unique_rows": [0, 10 * 10_000_000],
+          "scan_rows": [0, 10 * 13_000_000], "scan_bytes": [0, 0]}
+    r = bench.roofline_of(st, 128, k_i8, 3)
+    assert r["launch_ms"] == 0.4 and r["unique_bytes"] == 10_000_000 * 132 and r["bound"] == "hbm"
+    assert abs(r["achieved"] - 1.32e9 / 0.4e-3 / 1e9) < 1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    assert r["fp32_equivalent"]["unique_bytes"] == 10_000_000 * 512
+    assert r["frac"] <= 1.0 and r["mfma"]["frac"] < 0.1
