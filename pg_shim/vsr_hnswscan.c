@@ -52,7 +52,10 @@ hnswgettuple(IndexScanDesc scan, ScanDirection dir)
 			elog(ERROR, "non-MVCC snapshots are not supported with hnsw");	/* :203-204 */
 		/* the share lock pgvector takes around its page walk (:213-218) keeps vacuum's ordering with scans */
 		LockPage(scan->indexRelation, HNSW_SCAN_LOCK, ShareLock);
-		VsrRunSearch(scan, so, hnsw_ef_search);
+		if (vsr_pg_index_faithful)
+			VsrRunIndexSearch(scan, so, true, hnsw_ef_search);	/* HnswSearchLayer over pgvector's own graph, on the GPU */
+		else
+			VsrRunSearch(scan, so, hnsw_ef_search);
 		UnlockPage(scan->indexRelation, HNSW_SCAN_LOCK, ShareLock);
 		so->first = false;
 	}

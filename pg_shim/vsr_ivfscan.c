@@ -50,7 +50,10 @@ ivfflatgettuple(IndexScanDesc scan, ScanDirection dir)
 		if (!IsMVCCSnapshot(scan->xs_snapshot))
 			elog(ERROR, "non-MVCC snapshots are not supported with ivfflat");	/* :360-361 */
 		/* an ivfflat scan returns every row of the probed lists; the executor's LIMIT stops the popping */
-		VsrRunSearch(scan, so, VSR_MAX_K);
+		if (vsr_pg_index_faithful)
+			VsrRunIndexSearch(scan, so, false, ivfflat_probes);	/* GetScanLists + GetScanItems over pgvector's own lists */
+		else
+			VsrRunSearch(scan, so, VSR_MAX_K);
 		so->first = false;
 	}
 	return VsrNextTuple(scan, so);

@@ -27,6 +27,7 @@
 
 int			vsr_pg_device = 0;
 int			vsr_pg_mode = VSR_PG_MODE_POSTFILTER;
+bool		vsr_pg_index_faithful = false;
 
 static const struct config_enum_entry vsr_pg_mode_options[] = {
 	{"off", VSR_PG_MODE_OFF, false},
@@ -304,5 +305,9 @@ VsrPgInit(void)
 							 "off: unfiltered (RLS quals filter afterwards); prefilter: read only permitted rows; "
 							 "postfilter: per-row permission bit in the distance loop", &vsr_pg_mode,
 							 VSR_PG_MODE_POSTFILTER, vsr_pg_mode_options, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomBoolVariable("vsrbac.index_faithful",
+							 "Answer index scans with the index's own graph walk / list probe on the GPU (same candidates and "
+							 "recall as stock pgvector) instead of the exact filtered search", NULL, &vsr_pg_index_faithful,
+							 false, PGC_USERSET, 0, NULL, NULL, NULL);
 	MarkGUCPrefixReserved("vsrbac");
 }

@@ -38,6 +38,7 @@ typedef enum
 
 extern int	vsr_pg_device;		/* GUC vsrbac.device */
 extern int	vsr_pg_mode;		/* GUC vsrbac.mode */
+extern bool vsr_pg_index_faithful;	/* GUC vsrbac.index_faithful: reproduce the index's own answer (vsr_indexload.c) */
 
 /* One resident corpus per index relation, cached for the life of the backend (or of the sidecar). */
 typedef struct VsrPgCorpus
@@ -48,6 +49,8 @@ typedef struct VsrPgCorpus
 	int64		nrows;
 	ItemPointerData *tids;		/* caller row index (vsr_search's out_rows) -> heap TID */
 	bool		has_rbac;
+	vsr_hnsw   *graph;			/* vsrbac.index_faithful: pgvector's own graph / lists, loaded on first use */
+	vsr_ivf    *ivf;
 }			VsrPgCorpus;
 
 /* scan state shared by the two access methods: the first gettuple runs the whole search, later calls pop */
@@ -71,5 +74,10 @@ extern int32 VsrCurrentUserId(void);	/* current_user::int, the reference's RLS c
 extern vsr_filter *VsrFilterForCurrentUser(VsrPgCorpus * pc);	/* NULL when vsrbac.mode = off or no RBAC tables */
 extern void VsrRunSearch(IndexScanDesc scan, VsrPgScanOpaque so, int k_hint);	/* fills so->result_tids */
 extern bool VsrNextTuple(IndexScanDesc scan, VsrPgScanOpaque so);
+
+/* vsr_indexload.c */
+extern vsr_hnsw *VsrLoadHnswGraph(Relation index, VsrPgCorpus * pc);	/* index pages -> vsr_hnsw_load */
+extern vsr_ivf *VsrLoadIvfLists(Relation index, VsrPgCorpus * pc);	/* list pages -> vsr_ivf_load */
+extern void VsrRunIndexSearch(IndexScanDesc scan, VsrPgScanOpaque so, bool is_hnsw, int ef_or_probes);
 
 #endif							/* VSR_PG_H */
