@@ -54,6 +54,24 @@ VsrCheck(int status)
 static void
 vsr_pg_shutdown(int code, Datum arg)
 {
+	if (corpus_cache != NULL)
+	{
+		/* index structures before their corpus, corpora before the context (include/vsrbac.h) */
+		HASH_SEQ_STATUS seq;
+		VsrPgCorpus *pc;
+
+		hash_seq_init(&seq, corpus_cache);
+		while ((pc = (VsrPgCorpus *) hash_seq_search(&seq)) != NULL)
+		{
+			if (pc->graph != NULL)
+				(void) vsr_hnsw_free(pc->graph);
+			if (pc->ivf != NULL)
+				(void) vsr_ivf_free(pc->ivf);
+			if (pc->corpus != NULL)
+				(void) vsr_corpus_free(pc->corpus);
+		}
+		corpus_cache = NULL;
+	}
 	if (backend_ctx != NULL)
 	{
 		(void) vsr_close(backend_ctx);
@@ -154,6 +172,9 @@ VsrCorpusForIndex(Relation index)
 	pc = hash_search(corpus_cache, &indexoid, HASH_ENTER, &found);
 	if (found && pc->corpus != NULL)
 		return pc;
+	pc->corpus = NULL;
+	pc->graph = NULL;			/* loaded on first index-faithful scan (vsr_indexload.c) */
+	pc->ivf = NULL;
 
 	{
 		Relation	heap = table_open(index->rd_index->indrelid, AccessShareLock);
