@@ -486,6 +486,10 @@ def main():
                         roof["hbm_rate_measured"] = round(roof["traffic"] / (roof["launch_ms"] * 1e-3) / 1e9, 1)
         except (OSError, ValueError, KeyError, IndexError):
             pass
+        # the same bytes against the WALL time of a step (every kernel of the step, all batches in flight): what the job
+        # as a whole draws from HBM per second, independent of how many batches share the GPU
+        roof["per_step"] = {"achieved": round(roof["unique_bytes"] / (dt / args.steps) / 1e9, 1), "unit": "GB/s",
+                            "frac": round(roof["unique_bytes"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
         roof["workload_tag"] = tag
         wait_ms = r["stats"]["host_wait_ms"] / args.steps
         return {"value": round(nq * args.steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
