@@ -73,3 +73,23 @@ def test_pg_shim_calls_only_declared_abi_functions():
     helpers_called = set(re.findall(r"\b(Vsr[A-Z][A-Za-z0-9]+)\s*\(", text))
     helpers_defined = set(re.findall(r"^(Vsr[A-Z][A-Za-z0-9]+)\s*\(", text, flags=re.M))
     assert helpers_called <= helpers_defined, sorted(helpers_called - helpers_defined)
+
+
+def test_kernel_parameter_blocks_are_value_initialised():
+    """Every kernel parameter block (ScanParams, SelectParams, RerankParams, StageParams, HnswParams, ...) is declared
+    `T x{};`.  The round-2 GPU memory fault was a `StageParams st;` at one call site whose newly added pointer fields
+    (the int8 query planes) kept stack garbage and were dereferenced by stage_kernel."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "vectorsearch-rbac_amd", "csrc")
+    names = set()
+    for path in glob.glob(os.path.join(csrc, "*")):
+        names |= set(re.findall(r"struct\s+(\w+Params)\b", open(path).read()))
+    assert {"ScanParams", "SelectParams", "RerankParams", "StageParams", "HnswParams"} <= names
+    bad = []
+    for path in glob.glob(os.path.join(csrc, "*")):
+        for ln, line in enumerate(open(path).read().splitlines(), 1):
+            for nm in names:
+                if re.search(rf"^\s*(?:vsr::)?{nm}\s+\w+\s*;", line):
+                    bad.append(f"{os.path.basename(path)}:{ln}: {line.strip()}")
+    assert not bad, bad

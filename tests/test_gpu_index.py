@@ -187,3 +187,60 @@ def test_hnsw_search_matches_the_oracle(ctx, oracle, hnsw20k, ef):
             assert (resf.block_ids[i, keep.size:] == -1).all()
     gpu.free()
     corpus.free()
+
+
+def test_index_caches_forget_freed_filters(ctx, oracle, hnsw20k):
+    """The index-side caches (IVFFlat view-order bitmaps and probe parts, HNSW row bitmaps) are keyed by the filter's
+    never-reused id and purged when the filter dies: a filter created after another one was freed -- typically at the
+    SAME address -- or after a second vsr_rbac_load must never inherit the dead filter's permissions."""
+    import vsrbac
+    x, blk, doc, oh = hnsw20k
+    n = len(x)
+    rng = np.random.default_rng(97)
+    corpus = ctx.load_corpus(x, blk, doc)
+    oivf = OracleIvf(oracle, "l2", x, lists=20, seed=5)
+    ivf = corpus.load_ivf(oivf.centers, oivf.assign)
+    hnsw = corpus.load_hnsw(oh.export())
+    ndocs = int(doc.max())
+    q = x[rng.integers(0, n, 12)]
+    docs_a = np.arange(1, ndocs // 2 + 1, dtype=np.int32)
+    docs_b = np.arange(ndocs // 2 + 1, ndocs + 1, dtype=np.int32)
+
+    def check(flt, allowed_docs):
+        allowed = set(int(d) for d in allowed_docs)
+        r1 = ivf.search(q, 50, 20, "l2", [flt] * len(q))                  # probes = lists: the exact filtered scan
+        r2, _ = hnsw.search(q, 50, 200, "l2", [flt] * len(q))
+        mask = np.isin(doc, np.asarray(sorted(allowed), dtype=np.int32)).astype(np.uint8)
+        for i in range(len(q)):
+            for r in (r1, r2):
+                got = r.doc_ids[i, :r.counts[i]]
+                assert set(got.tolist()) <= allowed, (i, sorted(set(got.tolist()) - allowed)[:5])
+            idx, dist = oracle.filtered_topk("l2", x, q[i], 50, doc, blk, mask)
+            np.testing.assert_array_equal(r1.rows[i, :r1.counts[i]], idx)
+            rows_o, _, _, _ = oh.search(q[i], 200)
+            keep = rows_o[mask[rows_o] != 0][:50]
+            np.testing.assert_array_equal(r2.rows[i, :r2.counts[i]], keep)
+
+    for _ in range(3):                                                     # free, re-create: the allocator hands the address back
+        fa = corpus.filter_from_documents(docs_a)
+        check(fa, docs_a)
+        fa.free()
+        fb = corpus.filter_from_documents(docs_b)
+        check(fb, docs_b)
+        fb.free()
+    ma = np.isin(doc, docs_a).astype(np.uint8)
+    for mode in (vsrbac.RANGES, vsrbac.BITMAP):
+        fa = corpus.filter_from_bytemask(ma, mode)
+        check(fa, docs_a)
+        fa.free()
+        fb = corpus.filter_from_bytemask(1 - ma, mode)
+        check(fb, docs_b)
+        fb.free()
+    # role filters are cached by the corpus and deleted by the next vsr_rbac_load
+    for docs_now in (docs_a, docs_b, docs_a):
+        corpus.load_rbac([(1, 1)], [(1, int(d)) for d in docs_now])
+        for mode in (vsrbac.RANGES, vsrbac.BITMAP):
+            check(corpus.filter_for_user(1, mode), docs_now)
+    hnsw.free()
+    ivf.free()
+    corpus.free()

@@ -275,6 +275,9 @@ hipError_t launch_select(const SelectParams& p, uint32_t n_queries, int threads,
 uint32_t select_wave_fanin(uint32_t kp);
 uint32_t select_cap(uint32_t k, int threads);
 // Per-batch staging (one launch): descriptor block host -> device, queries padded to the row stride, |q|^2, flag / seed init.
+// Always declared value-initialised (`StageParams st{};`): the kernel takes a null pointer for "not needed".  A field added
+// here and set at one call site only, with the struct left uninitialised at the other, was the round-2 memory fault
+// ("The round-2 GPU memory fault"); tests/test_abi_cpu.py keeps every *Params declaration value-initialised.
 struct StageParams {
     const uint4* src16;            // pinned host memory as the device sees it
     uint4*       dst16;

@@ -56,6 +56,10 @@ static int fail(int status, const char* fmt, ...)
 struct DevBuf {
     void*  p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return VSR_OK;
@@ -80,6 +84,10 @@ struct DevBuf {
 struct PinBuf {
     void*  p = nullptr;
     size_t cap = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() { release(); }
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return VSR_OK;
@@ -171,24 +179,19 @@ struct vsr_ctx {
             (void) hipEventDestroy(ep.b);
         }
         for (auto ev : event_pool) (void) hipEventDestroy(ev);
-        d_desc.release();
-        d_partial.release();
-        d_cand.release();
-        d_flags.release();
-        d_tau.release();
-        d_samp.release();
-        d_qcnt.release();
-        d_out.release();
-        d_misc.release();
-        h_desc.release();
-        h_out.release();
+        // (every DevBuf / PinBuf member releases itself: ~DevBuf, ~PinBuf)
         if (desc_done) (void) hipEventDestroy(desc_done);
         if (d_flag_total) (void) hipFree(d_flag_total);
         if (own_stream) (void) hipStreamDestroy(own_stream);
     }
 };
 
+static std::atomic<uint64_t> g_filter_id{0};
+
 struct vsr_filter {
+    // never reused, unlike the address: what the index-side caches (vsr_ivf::parts / view_bitmaps, vsr_hnsw::bitmaps) are
+    // keyed by, so that a filter allocated where a freed one used to live can never inherit that filter's permissions
+    const uint64_t id = g_filter_id.fetch_add(1, std::memory_order_relaxed) + 1;
     vsr_corpus* corpus = nullptr;
     int         mode = VSR_FILTER_RANGES;
     bool        cached = false;
@@ -251,6 +254,9 @@ struct vsr_corpus {
     std::vector<vsr_filter*> class_filters;          // per class, built on first use (RANGES, owned by the corpus)
     std::vector<vsr_filter*> class_bitmap_filters;   // per class, BITMAP mode: aligned windows + the class's own bitmap
     uint32_t* d_doc_class = nullptr;                 // class of every document (device copy of doc_class)
+    // indexes loaded over this corpus: a filter that dies (vsr_filter_free, vsr_rbac_load) is purged from their caches
+    std::vector<struct vsr_ivf*>  ivf_indexes;
+    std::vector<struct vsr_hnsw*> hnsw_indexes;
 
     ~vsr_corpus();                 // frees the device arrays and cached filters (also on vsr_corpus_load's error returns)
 };
@@ -441,6 +447,8 @@ extern "C" int vsr_stats_reset(vsr_ctx* ctx)
 // corpus
 // ---------------------------------------------------------------------------------------------
 static void drop_cached_filters(vsr_corpus* c);
+// index-side caches derived from filters (defined with the indexes): drop what belongs to `f` (nullptr: everything)
+static void purge_index_caches(vsr_corpus* c, const vsr_filter* f);
 static void ranges_to_tiles(const std::vector<std::pair<uint32_t, uint32_t>>& ranges, int rw, std::vector<uint2>& tiles);
 
 extern "C" int vsr_corpus_free(vsr_corpus* c)
@@ -596,6 +604,7 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
 // ---------------------------------------------------------------------------------------------
 static void drop_cached_filters(vsr_corpus* c)
 {
+    purge_index_caches(c, nullptr);                  // the indexes' view-order bitmaps and probe parts of every filter
     for (vsr_filter* f : c->class_filters)
         if (f) {
             if (f->d_tiles) (void) hipFree(f->d_tiles);
@@ -1032,6 +1041,7 @@ extern "C" int vsr_filter_free(vsr_filter* f)
     if (!f || f->cached) return VSR_OK;    // cached filters belong to the corpus
     (void) hipSetDevice(f->corpus->ctx->device);
     (void) hipStreamSynchronize(f->corpus->ctx->stream);
+    purge_index_caches(f->corpus, f);
     free_filter(f);
     return VSR_OK;
 }
@@ -2497,8 +2507,8 @@ struct vsr_ivf {
     std::vector<uint32_t> list_start;                // lists + 1 offsets into the view
     std::vector<vsr_filter*> list_filters;           // one RANGES filter per list (tiles over the view)
     struct ViewBitmap { uint64_t* d = nullptr; std::vector<uint64_t> h; };
-    std::map<const vsr_filter*, ViewBitmap> view_bitmaps;                 // a base filter as a bitmap in view order
-    std::map<std::pair<const vsr_filter*, int>, vsr_filter*> parts;       // (base filter, list) -> part of a probe
+    std::map<uint64_t, ViewBitmap> view_bitmaps;                          // a base filter (by vsr_filter::id) as a bitmap in view order
+    std::map<std::pair<uint64_t, int>, vsr_filter*> parts;                // (base filter id, list) -> part of a probe
     DevBuf d_q, d_probe;
 };
 
@@ -2508,6 +2518,10 @@ extern "C" int vsr_ivf_free(vsr_ivf* ivf)
     if (ivf->main) {
         (void) hipSetDevice(ivf->main->ctx->device);
         (void) hipStreamSynchronize(ivf->main->ctx->stream);
+    }
+    if (ivf->main) {
+        auto& reg = ivf->main->ivf_indexes;
+        reg.erase(std::remove(reg.begin(), reg.end(), ivf), reg.end());
     }
     for (auto& kv : ivf->parts) delete kv.second;    // tiles / bitmaps are borrowed
     for (auto& kv : ivf->view_bitmaps)
@@ -2588,6 +2602,7 @@ extern "C" int vsr_ivf_load(vsr_corpus* c, const float* centers, int lists, cons
         f->allowed_rows = f->scanned_rows = s1 - s0;
         ivf->list_filters[(size_t) l] = f.release();
     }
+    c->ivf_indexes.push_back(ivf.get());
     *out = ivf.release();
     return VSR_OK;
 }
@@ -2599,7 +2614,7 @@ static int ivf_part(vsr_ivf* ivf, const vsr_filter* bf, int list, vsr_filter** o
         *out = ivf->list_filters[(size_t) list];
         return VSR_OK;
     }
-    auto key = std::make_pair(bf, list);
+    auto key = std::make_pair(bf->id, list);
     auto it = ivf->parts.find(key);
     if (it != ivf->parts.end()) {
         *out = it->second;
@@ -2607,7 +2622,7 @@ static int ivf_part(vsr_ivf* ivf, const vsr_filter* bf, int list, vsr_filter** o
     }
     vsr_corpus* v = ivf->view;
     vsr_ctx* ctx = v->ctx;
-    auto& vb = ivf->view_bitmaps[bf];
+    auto& vb = ivf->view_bitmaps[bf->id];
     if (!vb.d) {
         const size_t words = bitmap_words(v->n);
         HIPCHK(hipMalloc(&vb.d, words * sizeof(uint64_t)));
@@ -2743,7 +2758,7 @@ struct vsr_hnsw {
     int32_t n_elem = 0, entry = -1, entry_level = -1, m = 0, max_level = 1;
     int32_t *d_elem_row = nullptr, *d_level = nullptr, *d_nbr0 = nullptr, *d_up_slot = nullptr, *d_up_nbr = nullptr,
             *d_tid_count = nullptr, *d_tids = nullptr;
-    std::map<const vsr_filter*, uint64_t*> bitmaps;  // filters without a full bitmap of their own, as one
+    std::map<uint64_t, uint64_t*> bitmaps;           // filters (by vsr_filter::id) without a full bitmap of their own, as one
     DevBuf d_q, d_vis, d_out, d_bm;
     PinBuf h_out;
 };
@@ -2754,6 +2769,10 @@ extern "C" int vsr_hnsw_free(vsr_hnsw* h)
     if (h->corpus) {
         (void) hipSetDevice(h->corpus->ctx->device);
         (void) hipStreamSynchronize(h->corpus->ctx->stream);
+    }
+    if (h->corpus) {
+        auto& reg = h->corpus->hnsw_indexes;
+        reg.erase(std::remove(reg.begin(), reg.end(), h), reg.end());
     }
     void* ptrs[] = {h->d_elem_row, h->d_level, h->d_nbr0, h->d_up_slot, h->d_up_nbr, h->d_tid_count, h->d_tids};
     for (void* p : ptrs)
@@ -2814,8 +2833,40 @@ extern "C" int vsr_hnsw_load(vsr_corpus* c, int m, int32_t n_elem, int32_t entry
         vsr_hnsw_free(h.release());
         return rc;
     }
+    c->hnsw_indexes.push_back(h.get());
     *out = h.release();
     return VSR_OK;
+}
+
+// A filter of the corpus is about to die (vsr_filter_free) or all of them are (vsr_rbac_load, corpus teardown): the
+// indexes forget what they derived from it.  The caller has synchronised the corpus's stream.
+static void purge_index_caches(vsr_corpus* c, const vsr_filter* f)
+{
+    for (vsr_ivf* ivf : c->ivf_indexes) {
+        for (auto it = ivf->parts.begin(); it != ivf->parts.end();) {
+            if (!f || it->first.first == f->id) {
+                delete it->second;                           // tiles / bitmap are borrowed
+                it = ivf->parts.erase(it);
+            } else
+                ++it;
+        }
+        for (auto it = ivf->view_bitmaps.begin(); it != ivf->view_bitmaps.end();) {
+            if (!f || it->first == f->id) {
+                if (it->second.d) (void) hipFree(it->second.d);
+                it = ivf->view_bitmaps.erase(it);
+            } else
+                ++it;
+        }
+    }
+    for (vsr_hnsw* h : c->hnsw_indexes) {
+        for (auto it = h->bitmaps.begin(); it != h->bitmaps.end();) {
+            if (!f || it->first == f->id) {
+                if (it->second) (void) hipFree(it->second);
+                it = h->bitmaps.erase(it);
+            } else
+                ++it;
+        }
+    }
 }
 
 // the rows a filter admits as a bitmap over internal rows
@@ -2826,14 +2877,14 @@ static int hnsw_filter_bitmap(vsr_hnsw* h, const vsr_filter* f, const uint64_t**
         *out = f->d_bitmap;
         return VSR_OK;
     }
-    auto it = h->bitmaps.find(f);
+    auto it = h->bitmaps.find(f->id);
     if (it == h->bitmaps.end()) {
         uint64_t* d = nullptr;
         const size_t words = bitmap_words(c->n);
         HIPCHK(hipMalloc(&d, words * sizeof(uint64_t)));
         HIPCHK(hipMemsetAsync(d, 0, words * sizeof(uint64_t), c->ctx->stream));
         HIPCHK(launch_view_bitmap(nullptr, (uint32_t) c->n, f->d_tiles, f->n_tiles, f->d_bitmap, d, c->ctx->stream));
-        it = h->bitmaps.emplace(f, d).first;
+        it = h->bitmaps.emplace(f->id, d).first;
     }
     *out = it->second;
     return VSR_OK;
