@@ -104,6 +104,10 @@ struct ScanParams {
     const uint4*     scr;          // [n_rows][pstride4] 16-byte chunks
     const uint4*     q_scr;        // [n_slots][pstride4]
     uint32_t         pstride4;     // 16-byte chunks per corpus plane row (plane_stride4)
+    // K2g coarse planes (vsr_gemm.h): hi = bf16(x) only, rows of cstride4 16-byte chunks (d padded to whole 64-element K-steps)
+    const uint4*     scr_c;        // [n_rows][cstride4]
+    const uint4*     q_scr_c;      // [n_slots][cstride4]
+    uint32_t         cstride4;
     uint32_t         plane_ho;     // plane kind: 0 bf16 hi + mid; 1 bf16 hi only (every element exactly a bf16 value), 128
                                    // floats per stage; 2 int8 (u8-exact corpus and queries, x - 128; L2; 128 bytes per row)
     // K2w candidates: one buffer of capq keys per query slot, filled with returning atomics on qcnt (may exceed capq)
@@ -253,6 +257,14 @@ inline bool mfmaw_supported(uint32_t stride4) { return stride4 >= 16 && stride4 
 // 2): 128, two groups per wave
 inline int  mfmaw_qmax(uint32_t pstride4, bool ho) { return pstride4 / 16 > (ho ? 2u : 3u) ? 128 : 64; }
 hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
+// K2g (vsr_gemm.h): long rows, passes of up to 256 queries, 256 x 256 tiles with both operands in LDS, ONE bf16 product
+// per element on the coarse planes (hi = bf16(x) only; rows padded to whole 64-element K-steps)
+constexpr uint32_t GM_QMAX = 256;
+inline uint32_t coarse_stride4(int dim) { return 8u * (uint32_t) ((dim + 63) / 64); }
+// relative error bound of the coarse product xh * qh accumulated in fp32: |dot_s - dot| <= g |x| |q|
+inline float coarse_err_g(int dim) { return 3.9138794e-3f + (float) (dim + 64) * 5.9604645e-8f; }     // 2^-8 (1 + 2^-9) + ...
+hipError_t launch_gemm(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);
+hipError_t launch_split_coarse(const float4* rows, uint32_t n_rows, uint32_t stride4, uint4* scr_c, uint32_t cstride4, hipStream_t s);
 // Screening planes: element x = hi + mid + e with hi = bf16(x), mid = bf16(x - hi) (|e| <= 2^-18 |x|).  A plane row holds,
 // for every 64-float stage s, 8 chunks of 8 hi values followed by 8 chunks of 8 mid values (16 bytes each, zero padded):
 // the same 256 bytes per row and stage as the fp32 image, but ready for v_mfma_f32_16x16x32_bf16 (16x the fp32 rate).
@@ -295,6 +307,8 @@ struct StageParams {
     uint64_t*    tau;              // [nq] <- KEY_EMPTY (no seed)
     uint32_t*    qcnt;             // [nq] <- 0: K2w candidate counts (nullptr: not used)
     uint32_t*    scnt;             // [nq] <- 0: K2w sample counts
+    uint4*       q_scr_c;          // [nq][cstride4] coarse planes of the queries (hi = bf16(q) only), nullptr: not needed
+    uint32_t     cstride4;
     uint4*       q_scr8;           // [nq][8] int8 planes of the queries (q - 128, 16 per chunk), nullptr: not needed
     float*       q_norm2_8;        // [nq] sum (q - 128)^2 over the padded row
     uint32_t*    q8_bad;           // [nq] <- 1 for a query that is not integer-valued in 0..255 (select_rerank flags it)

@@ -1,0 +1,365 @@
+// vsr_gemm.h — K2g: the batched-query x corpus GEMM path for LONG rows (d > 192: BASELINE configs 3 / 5's 768-d rows).
+//
+// K2w (vsr_mfmaw.h) keeps the B fragments of <= 128 queries in registers and stages 64 rows per workgroup.  For long rows
+// that shape is bound by the path from L2 into the CU, not by the matrix pipe: per 64-float stage a workgroup pulls 16 KB
+// of rows and 32 KB of query fragments for 48 MFMAs per wave -- ~60 bytes per CU cycle against the ~30 the CU can take in
+// (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 66-73 GB/s per CU from L2); the round-2 counters showed exactly
+// that: matrix pipe 26 % busy, waves waiting.  K2g is shaped like a GEMM instead:
+//
+//   * tile = 256 rows x 256 queries per workgroup of 8 waves (2 x 4 waves, 128 x 64 outputs each = 8 x 4 blocks of
+//     v_mfma_f32_16x16x32_bf16, 128 accumulator registers per lane); BOTH operands go through LDS, so a K-step of 64
+//     elements costs (256 + 256) x 128 bytes for 64 MFMAs per wave: 32 bytes per CU cycle at full matrix rate;
+//   * operands are written into LDS by the load itself (global_load_lds_dwordx4: no staging registers, no ds_write), the
+//     XOR swizzle of the 128-byte LDS rows is applied on the SOURCE address (cdna_hip_programming.md, rule 21);
+//   * two stage buffers; the loads of K-step s + 1 are in flight under the MFMAs of step s, one barrier per K-step;
+//   * ONE product per element: the COARSE screening planes hold only hi = bf16(x) (vsr_corpus::d_scr_c), so a dot
+//     product is x.q ~ xh.qh with |error| <= g |x||q|, g = 2^-8 (1 + 2^-9) + (d + 64) 2^-24 (bf16 rounds to nearest:
+//     2^-9 relative per operand; fp32 accumulation).  That is 1/3 of K2w's products and 1/2 of its bytes.  The
+//     screening only decides which kp candidates per query survive; select_rerank_kernel recomputes vector.c's exact
+//     arithmetic for them and FLAGS a query unless the kept / dropped gap exceeds the bound, exactly as for K2w -- a
+//     coarser screen needs a larger kp (the planner takes 4k) and flags sooner; a flagged query is re-run on the fine
+//     planes (K2w) and, if still unproven, on the exact path (vsr_search, vsr_search_device_exact);
+//   * thresholds are folded into the accumulators: for L2 the chain starts at (tau - |q|^2) / 2, so that "candidate" is
+//     ONE compare per (row, query) pair, acc >= |x|^2 / 2 (IP: start at tau, compare with 0; cosine: compare with
+//     (1 - tau) |q| |x|); survivors (~1 in 5000 pairs) are appended to their query's buffer with one atomic each.
+//
+// The same kernel is its own sample pass (SAMPLE: every ss-th tile of a workgroup, open thresholds, one minimum per
+// query column and wave-tile), feeding seed_select_kernel like K2w's.
+//
+// Row mapping: a 256-row tile is 256 / rw list tiles of the pass (ScanGroup::tiles), resolved by threads 0..255 one
+// tile ahead in three steps spread over three K-steps (descriptor -> row -> permission bit and |row|^2), each step's
+// loads being complete at the next K-step's barrier anyway, so the mapping never stalls anybody.
+#pragma once
+#include <type_traits>
+#include "vsr_device.h"
+#include "vsr_topk.h"
+#include "vsr_mfma.h"
+
+namespace vsr {
+
+constexpr int GM_THREADS = 512;
+constexpr int GM_BM = 256;                 // rows per workgroup tile
+constexpr int GM_BN = 256;                 // query slots per pass
+constexpr int GM_KC = 8;                   // 16-byte chunks (8 bf16) per row and K-step: 64 elements, 128 bytes
+constexpr size_t GM_STAGE_U4 = (size_t) (GM_BM + GM_BN) * GM_KC;                  // uint4 per stage buffer (64 KB)
+inline size_t gemm_lds_bytes() { return 2 * GM_STAGE_U4 * 16 + 2 * GM_BM * 8 + GM_BN * 20 + 16; }
+
+using lds_u4 = __attribute__((address_space(3))) uint4;
+
+template <int METRIC, bool SAMPLE>
+__global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;                                                  // 128-row half of the tile
+    const int wn = wave & 3;                                                   // 64-query quarter of the pass
+
+    uint32_t lo = 0, mapped_block = 0;
+    if (p.block_map) {
+        const uint2 m = p.block_map[blockIdx.x];
+        if (m.x == 0xFFFFFFFFu) return;                                        // padding workgroup of a short XCD lane
+        lo = m.x;
+        mapped_block = m.y;
+    } else {
+        uint32_t hi = p.n_groups;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (p.groups[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
+        }
+    }
+    const ScanGroup grp = p.groups[lo];
+    const uint32_t local_block = p.block_map ? mapped_block : blockIdx.x - grp.block_begin;
+    const auto g_tiles = as_global(grp.tiles);
+    const auto g_bitmap = as_global(grp.bitmap);
+    const auto g_norm2 = as_global(p.norm2);
+    const auto g_rank = as_global(p.rank);
+
+    // LDS: [2 stage buffers: 256 row slots then 256 query slots, 8 chunks each | row ring: index, threshold | columns]
+    uint4*   stage = reinterpret_cast<uint4*>(smem);
+    int32_t* rowidx = reinterpret_cast<int32_t*>(smem + 2 * GM_STAGE_U4 * 16);  // [2][256]
+    float*   rowval = reinterpret_cast<float*>(rowidx + 2 * GM_BM);            // [2][256] what a candidate's acc must reach (NaN: no row)
+    float4*  colc = reinterpret_cast<float4*>(rowval + 2 * GM_BM);             // [256] {acc start, compare scale, |q|^2, slot bits}
+    float*   collim = reinterpret_cast<float*>(colc + GM_BN);                   // [256] the threshold itself (generic epilogue)
+    uint32_t* s_open = reinterpret_cast<uint32_t*>(collim + GM_BN);             // any query column without a threshold
+    // (all LDS lives in the one dynamic array: a second __shared__ object beside LDS-DMA staging can cost a vmcnt(0) per
+    // fragment read, cdna_hip_programming.md "Three .s-level traps")
+
+    const uint32_t cstride4 = p.cstride4;                                      // chunks per coarse plane row
+    const uint32_t nks = cstride4 / GM_KC;                                     // K-steps per tile (>= 4)
+    const uint32_t q_count = grp.q_count;
+
+    // ---- query columns: thresholds folded into what the accumulators start from ----
+    if (tid == 0) *s_open = 0u;
+    __syncthreads();
+    if (tid < GM_BN) {
+        const bool qok = (uint32_t) tid < q_count;
+        const uint32_t slot = p.q_slots[grp.q_begin + (qok ? (uint32_t) tid : 0u)];
+        const uint64_t tau = (!SAMPLE && p.tau_init) ? p.tau_init[slot] : KEY_EMPTY;
+        const bool open = tau == KEY_EMPTY;
+        const float lim = mono_to_float((uint32_t) (tau >> 32));
+        const float qn = p.q_norm2[slot];
+        float start = 0.0f, scale = 0.0f;
+        if (!SAMPLE && !open) {
+            if constexpr (METRIC == M_L2) start = 0.5f * (lim - qn);
+            else if constexpr (METRIC == M_IP) start = lim;
+            else scale = (1.0f - lim) * sqrtf(qn);
+        }
+        if (!qok) {                                                            // pad column: nothing is ever a candidate
+            if constexpr (METRIC == M_COSINE) scale = __builtin_inff();
+            else start = -__builtin_inff();
+        }
+        if (qok && open) *s_open = 1u;
+        colc[tid] = make_float4(start, scale, qn, __uint_as_float(qok ? slot : 0xFFFFFFFFu));
+        collim[tid] = !qok ? -__builtin_inff() : open ? __builtin_inff() : lim;
+    }
+    // open thresholds (a query whose sample was too thin; the sample pass itself): the generic epilogue
+    __syncthreads();
+    const bool generic = SAMPLE || lds_peek(s_open) != 0u;
+
+    // ---- this workgroup's tiles ----
+    const uint32_t rw = p.rw, tps = GM_BM / rw;                                // list tiles per 256-row tile
+    const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
+    const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
+    const uint32_t n_super = (t1 - t0 + tps - 1) / tps;
+    const uint32_t ss = p.sample_stride;
+    const uint32_t n_it = (n_super + ss - 1) / ss;
+    if (n_it == 0) return;
+    const uint32_t tile_last = grp.n_tiles - 1u;
+    const uint32_t last_row = p.n_rows - 1u;
+
+    // row mapping of tile it_ in three steps (threads 0..255, slot = tid); each step consumes the previous step's loads
+    uint2    m_desc = make_uint2(0u, 0u);
+    int32_t  m_row = -1;
+    uint64_t m_bw = ~0ull;
+    float    m_nrm = 0.0f;
+    auto map_fetch = [&](uint32_t it_) {
+        const uint32_t t = t0 + it_ * ss * tps + (uint32_t) (tid & (GM_BM - 1)) / rw;
+        const bool ok = it_ < n_it && t < t1;
+        const uint2 d = load_tile(g_tiles, t < tile_last ? t : tile_last);
+        m_desc = make_uint2(ok ? d.x : 0u, ok ? d.y : 0u);
+    };
+    auto map_rows = [&]() {
+        const uint32_t r = (uint32_t) (tid & (GM_BM - 1)) % rw;
+        const uint32_t rr = m_desc.x + r;
+        const bool ok = r < m_desc.y && rr <= last_row;
+        const uint32_t rc = ok ? rr : 0u;
+        m_row = ok ? (int32_t) rr : -1;
+        m_bw = g_bitmap ? g_bitmap[rc >> 6] : ~0ull;
+        m_nrm = g_norm2[rc];
+    };
+    auto map_commit = [&](uint32_t it_) {
+        if (tid < GM_BM) {
+            int32_t row = m_row;
+            if (row >= 0 && !((m_bw >> ((uint32_t) row & 63u)) & 1ull)) row = -1;
+            float v;
+            if (SAMPLE || generic) v = m_nrm;                                  // generic epilogue: |row|^2 itself
+            else if constexpr (METRIC == M_L2) v = 0.5f * m_nrm;
+            else if constexpr (METRIC == M_IP) v = 0.0f;
+            else v = sqrtf(m_nrm);
+            rowidx[(it_ & 1u) * GM_BM + tid] = row;
+            rowval[(it_ & 1u) * GM_BM + tid] = row >= 0 ? v : __builtin_nanf("");
+        }
+    };
+    map_fetch(0);
+    map_rows();
+    map_commit(0);
+    map_fetch(1);
+    __syncthreads();
+
+    // ---- operand staging: wave w issues the four 1-KB pieces 4w .. 4w+3 of the row half and of the query half ----
+    // piece = 8 slots x 128 bytes; lane -> (slot = 8 piece + (lane >> 3), LDS chunk = lane & 7) fetches source chunk
+    // (lane & 7) ^ (slot & 7) of that slot's plane row, so that LDS chunk c of slot s holds source chunk c ^ (s & 7)
+    const uint32_t l_slot = (uint32_t) lane >> 3;
+    const uint32_t l_src = ((uint32_t) lane & 7u) ^ l_slot;                     // slot & 7 == l_slot (pieces start at multiples of 8)
+    const uint4* a_src[4];
+    const uint4* b_src[4];
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+        const uint32_t qs = (uint32_t) (wave * 4 + pc) * 8u + l_slot;
+        const uint32_t slot = p.q_slots[grp.q_begin + (qs < q_count ? qs : 0u)];
+        b_src[pc] = p.q_scr_c + (size_t) slot * cstride4 + l_src;
+    }
+    auto set_rows = [&](uint32_t it_) {
+        const int32_t* ridx = rowidx + (it_ & 1u) * GM_BM;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int32_t r = ridx[(wave * 4 + pc) * 8 + (int) l_slot];
+            a_src[pc] = p.scr_c + (size_t) (uint32_t) (r < 0 ? 0 : r) * cstride4 + l_src;
+        }
+    };
+    auto issue = [&](uint32_t ks, int buf) {
+        lds_u4* dst = (lds_u4*) (stage + (size_t) buf * GM_STAGE_U4);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            __builtin_amdgcn_global_load_lds(as_global(a_src[pc] + ks * GM_KC), dst + (wave * 4 + pc) * 64, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(as_global(b_src[pc] + ks * GM_KC), dst + GM_BM * GM_KC + (wave * 4 + pc) * 64, 16, 0, 0);
+        }
+    };
+
+    // MFMA lane roles (16x16x32): A lane = (row li, k-octet kq); B / result lane = (k-octet kq | row quad kq, query jq)
+    const int li = lane & 15;
+    const int kq = lane >> 4;
+    f32x4 acc[8][4];
+
+    set_rows(0);
+    issue(0, 0);
+    int buf = 0;
+    for (uint32_t it = 0; it < n_it; ++it) {
+        // accumulators start from the folded thresholds of their query columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = generic ? 0.0f : colc[wn * 64 + j * 16 + li].x;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][j] = f32x4{s, s, s, s};
+        }
+        for (uint32_t ks = 0; ks < nks; ++ks) {
+            __syncthreads();                                                   // stage `buf` has landed everywhere; `buf ^ 1` is free
+            // row mapping of the next tile, one step per K-step (their loads were complete at the barrier above)
+            if (ks == 0) map_rows();
+            else if (ks == 1) { map_commit(it + 1); map_fetch(it + 2); }
+            const bool last = ks + 1 == nks;
+            if (last) set_rows(it + 1);                                        // (committed two barriers ago)
+            issue(last ? 0u : ks + 1, buf ^ 1);                                // past the last tile: row 0, never used
+            const uint4* sa = stage + (size_t) buf * GM_STAGE_U4 + (size_t) (wm * 128) * GM_KC;
+            const uint4* sb = stage + (size_t) buf * GM_STAGE_U4 + (size_t) (GM_BM + wn * 64) * GM_KC;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 bfr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = j * 16 + li;
+                    bfr[j] = __builtin_bit_cast(bf16x8, sb[q * GM_KC + ((kb * 4 + kq) ^ (q & 7))]);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bf16x8 afr[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = (h * 4 + i) * 16 + li;
+                        afr[i] = __builtin_bit_cast(bf16x8, sa[r * GM_KC + ((kb * 4 + kq) ^ (r & 7))]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+
+        // ---- epilogue: acc[i][j][r] belongs to row slot wm * 128 + i * 16 + kq * 4 + r and query column wn * 64 + j * 16 + li ----
+        const int32_t* ridx = rowidx + (it & 1u) * GM_BM + wm * 128;
+        const float* rval = rowval + (it & 1u) * GM_BM + wm * 128;
+        auto append = [&](uint32_t slot, float v, int32_t row) {
+            const uint32_t at = atomicAdd(p.qcnt + slot, 1u);
+            if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = make_key(v, g_rank ? g_rank[row] : (uint32_t) row);
+        };
+        if (!generic) {
+            float tr[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&rval[i * 16 + kq * 4]);
+                tr[i][0] = t4.x; tr[i][1] = t4.y; tr[i][2] = t4.z; tr[i][3] = t4.w;
+            }
+            float cs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = METRIC == M_COSINE ? colc[wn * 64 + j * 16 + li].y : 0.0f;
+            // first the wave-wide question "any candidate at all?": the largest acc - (what it must reach) of the lane,
+            // two VALU operations per pair and no lane masks (a NaN row threshold drops out of fmaxf)
+            float best = -__builtin_inff();
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (METRIC == M_COSINE) best = fmaxf(best, fmaf(-cs[j], tr[i][r], acc[i][j][r]));
+                        else best = fmaxf(best, acc[i][j][r] - tr[i][r]);
+                    }
+            const uint64_t any = __ballot(best >= 0.0f);
+            if (any) {                                                         // wave-uniform, rare: ~1 survivor per 5000 pairs
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bool c[4];
+                        bool hit = false;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (METRIC == M_COSINE) c[r] = acc[i][j][r] >= cs[j] * tr[i][r];
+                            else c[r] = acc[i][j][r] >= tr[i][r];
+                            hit |= c[r];
+                        }
+                        if (__ballot(hit)) {
+                            const float4 cc = colc[wn * 64 + j * 16 + li];
+                            const uint32_t slot = __float_as_uint(cc.w);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (c[r]) {
+                                    const int32_t row = ridx[i * 16 + kq * 4 + r];
+                                    float v;
+                                    if constexpr (METRIC == M_L2) v = fmaf(-2.0f, acc[i][j][r] - cc.x, 2.0f * tr[i][r] + cc.z);
+                                    else if constexpr (METRIC == M_IP) v = -(acc[i][j][r] - cc.x);
+                                    else v = 1.0f - acc[i][j][r] * rsqrtf(tr[i][r] * tr[i][r] * cc.z);
+                                    append(slot, v, row);
+                                }
+                        }
+                    }
+            }
+        } else {
+            // generic: the screening value of every valid pair.  SAMPLE keeps one minimum per query column and wave-tile
+            // (128 rows); an open threshold admits every valid pair (only planned for filters that fit the buffer)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 cc = colc[wn * 64 + j * 16 + li];
+                const uint32_t slot = __float_as_uint(cc.w);
+                const float lim = collim[wn * 64 + j * 16 + li];                // (generic main pass: columns with a threshold keep it)
+                uint64_t best = KEY_EMPTY;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int32_t row = ridx[i * 16 + kq * 4 + r];
+                        const float nx = rval[i * 16 + kq * 4 + r];
+                        const float v = screen_value<METRIC>(acc[i][j][r], nx, cc.z);
+                        if (row < 0 || slot == 0xFFFFFFFFu) continue;
+                        if constexpr (SAMPLE) {
+                            const uint64_t key = make_key(v, g_rank ? g_rank[row] : (uint32_t) row);
+                            best = key < best ? key : best;
+                        } else {
+                            if (!(v > lim)) append(slot, v, row);
+                        }
+                    }
+                if constexpr (SAMPLE) {
+                    uint64_t o = __shfl_xor(best, 16);
+                    best = o < best ? o : best;
+                    o = __shfl_xor(best, 32);
+                    best = o < best ? o : best;
+                    if (kq == 0 && best != KEY_EMPTY) {
+                        const uint32_t at = atomicAdd(p.qcnt + slot, 1u);
+                        if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = best;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int METRIC>
+hipError_t launch_gemm_metric(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
+{
+    const size_t lds = gemm_lds_bytes();
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(GM_THREADS), lds, s, p);
+        return hipGetLastError();
+    };
+    if (p.cstride4 < 4 * GM_KC || p.cstride4 % GM_KC != 0 || GM_BM % p.rw != 0) return hipErrorInvalidValue;
+    return p.sample_stride > 1 ? launch(gemm_screen_kernel<METRIC, true>) : launch(gemm_screen_kernel<METRIC, false>);
+}
+
+}  // namespace vsr

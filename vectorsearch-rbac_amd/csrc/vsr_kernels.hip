@@ -24,6 +24,20 @@ hipError_t launch_mfmaw_l2(const ScanParams&, uint32_t, hipStream_t);
 hipError_t launch_mfmaw_ip(const ScanParams&, uint32_t, hipStream_t);
 hipError_t launch_mfmaw_cosine(const ScanParams&, uint32_t, hipStream_t);
 
+hipError_t launch_gemm_l2(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_gemm_ip(const ScanParams&, uint32_t, hipStream_t);
+hipError_t launch_gemm_cosine(const ScanParams&, uint32_t, hipStream_t);
+
+hipError_t launch_gemm(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s)
+{
+    switch (metric) {
+    case M_L2:     return launch_gemm_l2(p, n_blocks, s);
+    case M_IP:     return launch_gemm_ip(p, n_blocks, s);
+    case M_COSINE: return launch_gemm_cosine(p, n_blocks, s);
+    default:       return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s)
 {
     switch (metric) {
@@ -628,6 +642,38 @@ hipError_t launch_split_planes8(const float4* rows, uint32_t n_rows, uint32_t st
     return hipGetLastError();
 }
 
+// Coarse planes (K2g): 8 consecutive floats -> one chunk of 8 bf16 values hi = bf16(x), round to nearest even; chunks past
+// the row's float4s are zero (rows are padded to whole 64-element K-steps)
+__device__ __forceinline__ uint4 coarse8(const float4* row, uint32_t stride4, uint32_t c)
+{
+    const float4 a = 2 * c < stride4 ? row[2 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = 2 * c + 1 < stride4 ? row[2 * c + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned short h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = __builtin_bit_cast(unsigned short, (__bf16) x[j]);
+    return make_uint4(h[0] | (uint32_t) h[1] << 16, h[2] | (uint32_t) h[3] << 16, h[4] | (uint32_t) h[5] << 16, h[6] | (uint32_t) h[7] << 16);
+}
+
+__global__ __launch_bounds__(256) void split_coarse_kernel(const float4* rows, uint32_t n_rows, uint32_t stride4, uint4* scr_c,
+                                                           uint32_t cstride4)
+{
+    const uint64_t total = (uint64_t) n_rows * cstride4;
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t) gridDim.x * 256) {
+        const uint32_t r = (uint32_t) (i / cstride4), c = (uint32_t) (i % cstride4);
+        scr_c[i] = coarse8(rows + (size_t) r * stride4, stride4, c);
+    }
+}
+
+hipError_t launch_split_coarse(const float4* rows, uint32_t n_rows, uint32_t stride4, uint4* scr_c, uint32_t cstride4, hipStream_t s)
+{
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t total = (uint64_t) n_rows * cstride4;
+    hipLaunchKernelGGL(split_coarse_kernel, dim3((uint32_t) std::min<uint64_t>((total + 255) / 256, 16384)), dim3(256), 0, s, rows,
+                       n_rows, stride4, scr_c, cstride4);
+    return hipGetLastError();
+}
+
 // Per-batch staging, see StageParams.  Workgroups [0, nq): one query each; the rest copy the descriptor block.
 __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
 {
@@ -655,6 +701,9 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
             split_row_item(reinterpret_cast<const float4*>(dst), p.qfloats / 4, p.q_scr + (size_t) s * qstride, item,
                            p.plane_ho != 0, 32u, 16u);
     }
+    if (p.q_scr_c)                                           // K2g: the query's coarse plane
+        for (uint32_t c = (uint32_t) tid; c < p.cstride4; c += 256)
+            p.q_scr_c[(size_t) s * p.cstride4 + c] = coarse8(reinterpret_cast<const float4*>(dst), p.qfloats / 4, c);
     if (p.q_scr8 && tid >= 64 && tid < 72) {                 // int8 path: the query as q - 128, validated
         const uint32_t c = (uint32_t) tid - 64;
         uint4 out;

@@ -171,6 +171,9 @@ struct vsr_ctx {
     bool no_xcd_map = false;       // VSR_NO_XCD_MAP=1: workgroups in pass order instead of XCD-aware bundles (A/B)
     bool no_mq = false;            // VSR_NO_MQ=1: keep shared passes on K1 (A/B measurements)
     bool no_wide = false;          // VSR_NO_WIDE=1: shared passes on K2 (wave-private tiles) instead of K2w (A/B)
+    bool no_gemm = false;          // VSR_NO_GEMM=1: wide passes over long rows on K2w instead of K2g (A/B)
+    int  screen_level = 2;         // search_impl -> make_plan: 2 = every screening tier, 1 = no coarse tier (K2g), 0 = exact only
+    bool last_coarse = false;      // the last search screened on the coarse planes: its flagged queries go to the fine tier first
 
     ~vsr_ctx()                     // also runs on vsr_open's error returns: nothing allocated so far is leaked
     {
@@ -228,6 +231,8 @@ struct vsr_corpus {
     uint2*      d_all_tiles = nullptr;   // identity tile list (K2w always walks an explicit list: unfiltered passes use this)
     uint32_t    pstride4 = 0;            // 16-byte chunks per plane row
     bool        scr_has_mid = true;      // false: every element is exactly a bf16 value (e.g. SIFT's 0..255 integers)
+    uint4*      d_scr_c = nullptr;       // K2g coarse planes (hi = bf16(x) only, rows padded to whole 64-element K-steps): long rows
+    uint32_t    cstride4 = 0;            // 16-byte chunks per coarse plane row
     uint4*      d_scr8 = nullptr;        // int8 planes (x - 128, 128 bytes per row): corpus of integers 0..255, d <= 128; L2 only
     float*      d_norm2_8 = nullptr;     // sum (x - 128)^2 per row
     float*      d_norm2_max = nullptr;   // max |row|^2 (error bound of K2 screening); +Inf if any |row|^2 is not finite
@@ -312,6 +317,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_MAX_QB"))) { ctx->max_qb = std::max(1, atoi(env)); ctx->max_qb_set = true; }
     if ((env = getenv("VSR_NO_MQ"))) ctx->no_mq = atoi(env) != 0;
     if ((env = getenv("VSR_NO_WIDE"))) ctx->no_wide = atoi(env) != 0;
+    if ((env = getenv("VSR_NO_GEMM"))) ctx->no_gemm = atoi(env) != 0;
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
@@ -463,7 +469,7 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
 vsr_corpus::~vsr_corpus()
 {
     drop_cached_filters(this);
-    void* ptrs[] = {d_rows, d_scr, d_scr8, d_norm2_8, d_all_tiles, d_doc_class, d_rank, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
+    void* ptrs[] = {d_rows, d_scr, d_scr_c, d_scr8, d_norm2_8, d_all_tiles, d_doc_class, d_rank, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
     for (void* p : ptrs)
         if (p) (void) hipFree(p);
 }
@@ -579,6 +585,14 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
             HIPCHK(hipMalloc(&c->d_all_tiles, all.size() * sizeof(uint2)));
             HIPCHK(hipMemcpy(c->d_all_tiles, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
             HIPCHK(hipStreamSynchronize(ctx->stream));
+            // long rows (the 768-d configurations) also get the COARSE planes of K2g: hi = bf16(x) alone, half the bytes of
+            // the hi + mid planes and one product per element; wide passes (> 128 queries per filter part) screen on them
+            if (mfmaw_qmax(c->pstride4, !c->scr_has_mid) > 64 && !getenv("VSR_NO_COARSE")) {
+                c->cstride4 = coarse_stride4(dim);
+                HIPCHK(hipMalloc(&c->d_scr_c, alloc_rows * (size_t) c->cstride4 * 16 + 1024));
+                HIPCHK(launch_split_coarse(c->d_rows, (uint32_t) n, c->stride4, c->d_scr_c, c->cstride4, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+            }
             // SIFT-like corpora (every element an integer 0..255, d <= 128) also get int8 planes: a quarter of the fp32
             // bytes per row and v_mfma_i32_16x16x64_i8; used for L2 searches whose queries are such integers too
             if (!c->scr_has_mid && dim <= 128 && !getenv("VSR_NO_INT8")) {
@@ -1066,6 +1080,7 @@ struct Plan {
     bool                     k2 = false;     // shared passes run on K2 / K2w (MFMA screening) + K5r
     bool                     k2w = false;    // ... on K2w: workgroup-shared row tiles, up to 128 queries per pass (vsr_mfmaw.h)
     bool                     int8 = false;   // ... on the corpus's int8 planes (L2, integer 0..255 rows and queries)
+    bool                     k2g = false;    // ... on K2g: long rows, 256-query passes, coarse planes (vsr_gemm.h); implies k2w
     uint32_t                 keep = 0;       // partial list length kp (K2: 2k screening survivors; else k)
     uint32_t                 rerank_base = 0;  // K2: first partial list holding the per-query screening survivors
     uint32_t                 n_scan_lists = 0;
@@ -1091,7 +1106,7 @@ struct Plan {
     void reset()                             // keeps the vectors' capacity: one plan per batch, no allocation once warm
     {
         q_slots.clear(); groups.clear(); list_ids.clear(); block_map.clear(); n_launch = 0; sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
-        n_blocks = 0; qi = 1; mq = false; k2 = false; k2w = false; int8 = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
+        n_blocks = 0; qi = 1; mq = false; k2 = false; k2w = false; int8 = false; k2g = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
         n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0; sel_wave = false;
         scan_pairs = 0; unique_rows = 0; kp_frac = 0; sample_stride = 1;
     }
@@ -1109,7 +1124,7 @@ struct PassItem {
 // ceil(queries of the class / qmax) times per class instead of once per role partition.
 // Returns false when the K2w plan it built cannot be seeded safely (the caller then plans again with allow_wide = false).
 static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, int metric, bool allow_screening,
-                      bool allow_wide, const vsr_filter* const* filters, Plan& plan)
+                      bool allow_wide, bool allow_gemm, const vsr_filter* const* filters, Plan& plan)
 {
     auto fof = [&](uint32_t q) { return filters ? filters[q] : nullptr; };
 
@@ -1177,7 +1192,21 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     const bool k2_ok = k2w_ok || (k2_any && mfma_cap_for_k(keep) <= 8192 && mfma_lds_bytes(c->stride4) <= 150 * 1024);
     int qmax;
     int wq = mfmaw_qmax(c->pstride4, !c->scr_has_mid);
-    if (wq > 64) {
+    // K2g (coarse planes, 256-query passes): when nearly all (part, query) items sit in parts seen by more than 128
+    // queries -- unfiltered batches, a few big partitions -- and the coarser screen's larger survivor list fits
+    const uint32_t keep_c = (uint32_t) std::max(4 * k, 128);
+    bool k2g = k2w_ok && allow_gemm && c->d_scr_c && !ctx->no_gemm && ctx->screen_level >= 2 && keep_c <= GQ_MAX_KP && !ctx->max_qb_set;
+    if (k2g) {
+        uint64_t big = 0, all = 0;
+        for (size_t g = 0; g < gcount.size(); ++g) {
+            const uint32_t cnt = gcount[g] - (g ? gcount[g - 1] : 0u);         // gcount holds end offsets after the scatter
+            all += cnt;
+            if (cnt > 128) big += cnt;
+        }
+        k2g = all > 0 && big * 10 >= all * 9;
+    }
+    if (k2g) wq = (int) GM_QMAX;
+    if (wq > 64 && !k2g) {
         // long rows: 128-query passes (two groups per wave: a heavier kernel that also fetches the second group's fragments
         // where a pass has none) pay when nearly all (part, query) items sit in parts seen by more than 64 queries --
         // unfiltered batches: 1M x 768 x 1000 queries 9.9 -> 7.9 ms; a role mix (1000 users over 100 roles) would lose:
@@ -1252,6 +1281,8 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     else if (plan.k2) plan.qmax = plan.qmax > 16 ? 32 : 16;
     plan.int8 = plan.k2w && c->d_scr8 && metric == VSR_METRIC_L2 && ctx->int8_this_call;
     if (plan.int8) plan.keep = (uint32_t) std::max(k, 32);  // exact screening: no second half of survivors to re-rank
+    plan.k2g = plan.k2w && k2g && !plan.int8;
+    if (plan.k2g) plan.keep = keep_c;                       // coarse screening: a wider survivor list for the exact re-rank
 
     int64_t total_rows = 0, total_cost = 0;
     for (auto& p : passes) {
@@ -1269,7 +1300,9 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     if (ctx->block_budget <= 0 && plan.qi == 4) {
         // K2w keeps 3 workgroups per CU resident and its passes differ a lot in cost per row: ~4 rounds of workgroups
         // even them out (10M rows, 1000 queries: main launch alone 0.97 -> 0.75 ms from 4 to 12 per CU)
-        const int64_t want = plan.k2w ? std::min<int64_t>(total_rows / 4096, 12 * cus) : std::min<int64_t>(total_rows / 13000, 16 * cus);
+        // (K2g: one 8-wave workgroup per CU; ~3 rounds, at least ~8 of its 256-row tiles per workgroup)
+        const int64_t want = plan.k2g ? std::min<int64_t>(total_rows / 2048, 3 * cus)
+                           : plan.k2w ? std::min<int64_t>(total_rows / 4096, 12 * cus) : std::min<int64_t>(total_rows / 13000, 16 * cus);
         if (want > budget) {
             budget = want;
             seed_div = std::max<uint32_t>(seed_div, (uint32_t) (budget / (2 * cus)));
@@ -1279,7 +1312,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         // the sample launch visits every ss-th tile: a workgroup of it is all prologue and memory latency, so it gets ONE
         // resident round of workgroups (each then walks ~12 tiles instead of three rounds walking 4: 72 -> ~45 us on the
         // 10M-row corpus); launches that fit one round anyway (a shard) keep the main launch's workgroups
-        const int64_t slots = (plan.int8 ? 4 : 3) * cus;
+        const int64_t slots = (plan.k2g ? 1 : plan.int8 ? 4 : 3) * cus;
         seed_div = (uint32_t) std::max<int64_t>(1, (budget + slots - 1) / slots);
     }
 
@@ -1368,9 +1401,10 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         plan.sample_stride = ctx->sample_stride;
         const double ss = plan.sample_stride;
         double frac = 1.0 / ss;
+        const double tile_rows = plan.k2g ? 256.0 : 64.0;   // rows per workgroup tile of the kernel
         for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
             const ScanGroup& gs = plan.groups_s[gi];
-            const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / 64.0);
+            const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / tile_rows);
             const double per_block = std::ceil(t64 / gs.n_blocks);
             const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
             if (t64 > 0) frac = std::max(frac, sampled / t64);
@@ -1390,14 +1424,15 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
                 const double allowed = f ? (double) f->allowed_rows : (double) c->n;
                 fine |= allowed / (64.0 * ss) < 4.0 * seed_m;
             }
+            if (plan.k2g) fine = false;                            // K2g: one minimum per column and 128-row wave-tile
             gs.partial_begin = fine ? 1u : 0u;                     // (K2w has no partial lists: the field carries the flag)
-            const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / 64.0);
+            const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / tile_rows);
             const double per_block = std::ceil(t64 / gs.n_blocks);
             const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
             const uint32_t ngt = (gs.q_count + 15) / 16;
-            const double waves_per_col = ngt == 1 ? 4.0 : ngt == 2 ? 2.0 : 1.0;     // row split (vsr_mfmaw.h)
+            const double waves_per_col = plan.k2g ? 2.0 : ngt == 1 ? 4.0 : ngt == 2 ? 2.0 : 1.0;     // row split (vsr_mfmaw.h)
             const double entries_per_tile = waves_per_col * (fine ? 4.0 : 1.0);
-            const double rows_per_entry = 64.0 / entries_per_tile;
+            const double rows_per_entry = tile_rows / entries_per_tile;
             const double p_entry = std::min(1.0, gdens[gi] * rows_per_entry);      // a bitmap may leave an entry without rows
             for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * entries_per_tile * p_entry;
         }
@@ -1511,7 +1546,9 @@ static std::string scan_kernel_name(const Plan& plan, const vsr_corpus* c, int m
     static const char* mname[] = {"L2", "IP", "COSINE", "L1"};
     char buf[160];
     const uint32_t nstage = (c->stride4 + 15) / 16;
-    if (plan.k2w && plan.int8)
+    if (plan.k2g)
+        snprintf(buf, sizeof buf, "vsr::gemm_screen_kernel<%s, SAMPLE=false> (K2g, bf16 coarse planes)", mname[metric]);
+    else if (plan.k2w && plan.int8)
         snprintf(buf, sizeof buf, "vsr::mfma_wide_kernel<%s, NCH=1, SAMPLE=false, PL=int8> (K2w, int8 planes)", mname[metric]);
     else if (plan.k2w)
         snprintf(buf, sizeof buf, "vsr::mfma_wide_kernel<%s, NCH=%u, SAMPLE=false, HO=%s> (K2w, bf16 %s planes)", mname[metric],
@@ -1541,7 +1578,8 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     const size_t off_q = 0;
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
     const size_t off_qp = align_up(off_qn + (size_t) nq * sizeof(float), 256);
-    const size_t off_q8 = align_up(off_qp + (size_t) nq * q_pstride * 16, 256);            // int8 query planes, |q-128|^2, validity
+    const size_t off_qc = align_up(off_qp + (size_t) nq * q_pstride * 16, 256);            // K2g: coarse query planes
+    const size_t off_q8 = align_up(off_qc + (plan.k2g ? (size_t) nq * c->cstride4 * 16 : 0), 256);   // int8 query planes, |q-128|^2, validity
     const size_t off_qn8 = align_up(off_q8 + (plan.int8 ? (size_t) nq * 128 : 0), 256);
     const size_t off_qb = align_up(off_qn8 + (plan.int8 ? (size_t) nq * sizeof(float) : 0), 256);
     const size_t off_g = align_up(off_qb + (plan.int8 ? (size_t) nq * sizeof(uint32_t) : 0), 256);    // copied from here on
@@ -1617,6 +1655,11 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         st.tau = ctx->d_tau.as<uint64_t>();
         st.qcnt = qcnt;
         st.scnt = scnt;
+        if (plan.k2g) {
+            st.q_scr = nullptr;                             // only the coarse planes are read
+            st.q_scr_c = reinterpret_cast<uint4*>(ds + off_qc);
+            st.cstride4 = c->cstride4;
+        }
         if (plan.int8) {
             if (!ctx->h_q8.p) {
                 if ((rc = ctx->h_q8.reserve(64))) return rc;
@@ -1651,6 +1694,12 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.pstride4 = 8;
         sp.plane_ho = 2u;
     }
+    if (plan.k2g) {
+        sp.scr_c = c->d_scr_c;
+        sp.q_scr_c = reinterpret_cast<const uint4*>(ds + off_qc);
+        sp.cstride4 = c->cstride4;
+    }
+    auto launch_pass = [&](uint32_t blocks) { return plan.k2g ? launch_gemm(sp, metric, blocks, ctx->stream) : launch_mfmaw(sp, metric, blocks, ctx->stream); };
     sp.q_slots = reinterpret_cast<const uint32_t*>(ds + off_qs);
     sp.kp = sp.k = kp;
     sp.qmax = plan.qmax;
@@ -1674,7 +1723,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.qcand = ctx->d_samp.as<uint64_t>();
         sp.qcnt = scnt;
         sp.capq = GQ_SAMPLE_CAP;
-        HIPCHK(launch_mfmaw(sp, metric, plan.n_blocks_s, ctx->stream));
+        HIPCHK(launch_pass(plan.n_blocks_s));
         HIPCHK(launch_seed_select(ctx->d_samp.as<uint64_t>(), scnt, GQ_SAMPLE_CAP, plan.kp_frac, ctx->d_tau.as<uint64_t>(),
                                   (uint32_t) nq, ctx->stream));
         if (a0) {
@@ -1703,7 +1752,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.qcnt = qcnt;
         sp.capq = GQ_CAP;
         if (!plan.block_map.empty() && !ctx->no_xcd_map) sp.block_map = reinterpret_cast<const uint2*>(ds + off_bm);
-        HIPCHK(launch_mfmaw(sp, metric, sp.block_map ? plan.n_launch : plan.n_blocks, ctx->stream));
+        HIPCHK(launch_pass(sp.block_map ? plan.n_launch : plan.n_blocks));
         if (e0) {
             HIPCHK(hipEventRecord(e1, ctx->stream));
             ctx->pending.push_back({e0, e1, 1});
@@ -1744,7 +1793,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     rr.qcand = ctx->d_cand.as<uint64_t>();
     rr.qcnt = qcnt;
     rr.capq = GQ_CAP;
-    rr.err_g = plane_err_g(c->dim);
+    rr.err_g = plan.k2g ? coarse_err_g(c->dim) : plane_err_g(c->dim);
     rr.qbad = plan.int8 ? reinterpret_cast<const uint32_t*>(ds + off_qb) : nullptr;
     rr.exact_screen = plan.int8 ? 1u : 0u;
     rr.seeded = 1;
@@ -1769,8 +1818,13 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
 // of the same device (vsr_search_device_on) so that two batches over one corpus can be in flight at once.
 static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, const float* d_queries, int nq, int dim, int k,
                        int metric, const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row,
-                       float* d_dist, int32_t* d_cnt, uint64_t* d_keys, bool allow_screening)
+                       float* d_dist, int32_t* d_cnt, uint64_t* d_keys, int level)
 {
+    // level: 2 = every screening tier (coarse planes for wide passes over long rows, K2g), 1 = fine planes only (K2w / K2),
+    // 0 = exact kernels only.  A query flagged at one level is re-run at the next lower one (host_search,
+    // vsr_search_device_exact).
+    const bool allow_screening = level >= 1;
+    ctx->screen_level = level;
     const auto h0 = std::chrono::steady_clock::now();
     struct HostTimer {
         vsr_ctx* ctx;
@@ -1803,10 +1857,15 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
     }
     static thread_local Plan plan;
     plan.reset();
-    if (!make_plan(ctx, c, nq, k, metric, allow_screening, true, filters, plan)) {
-        plan.reset();                                       // K2w could not be seeded safely: legacy shared passes
-        (void) make_plan(ctx, c, nq, k, metric, allow_screening, false, filters, plan);
+    if (!make_plan(ctx, c, nq, k, metric, allow_screening, true, true, filters, plan)) {
+        const bool was_gemm = plan.k2g;
+        plan.reset();                                       // K2g could not be seeded safely: K2w; K2w neither: legacy shared passes
+        if (!was_gemm || !make_plan(ctx, c, nq, k, metric, allow_screening, true, false, filters, plan)) {
+            plan.reset();
+            (void) make_plan(ctx, c, nq, k, metric, allow_screening, false, false, filters, plan);
+        }
     }
+    ctx->last_coarse = plan.k2g;
     if (plan.k2w) {
         ctx->host_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
         return search_wide(ctx, c, plan, h_queries, d_queries, nq, dim, k, metric, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys);
@@ -2202,7 +2261,7 @@ extern "C" int vsr_search_device_on(vsr_ctx* session, vsr_corpus* c, const float
         if ((rc = ctx->d_misc.reserve((size_t) nq * k * sizeof(int32_t)))) return rc;
         d_doc = ctx->d_misc.as<int32_t>();
     }
-    return search_impl(ctx, c, nullptr, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys, true);
+    return search_impl(ctx, c, nullptr, d_queries, nq, dim, k, metric, filters, d_blk, d_doc, d_row, d_dist, d_cnt, d_keys, 2);
 }
 
 extern "C" int vsr_search_device(vsr_corpus* c, const float* d_queries, int nq, int dim, int k, int metric,
@@ -2230,43 +2289,50 @@ extern "C" int vsr_search_device_exact(vsr_ctx* session, vsr_corpus* c, const fl
         if (flags[(size_t) i]) redo.push_back(i);
     if (redo.empty()) return VSR_OK;
     ctx->flagged_seen += (int64_t) redo.size();
-    const size_t nr = redo.size(), nk = nr * (size_t) k;
-    // workspace: [queries | block | row | doc | dist | keys | counts] of the flagged queries
-    const size_t o_q = 0, o_blk = align_up(o_q + nr * (size_t) dim * 4, 256), o_row = align_up(o_blk + nk * 8, 256),
-                 o_doc = align_up(o_row + nk * 8, 256), o_dist = align_up(o_doc + nk * 4, 256),
-                 o_key = align_up(o_dist + nk * 4, 256), o_cnt = align_up(o_key + nk * 8, 256),
-                 total = align_up(o_cnt + nr * 4, 256);
-    if ((rc = ctx->d_redo.reserve(total))) return rc;
-    char* w = ctx->d_redo.as<char>();
-    std::vector<const vsr_filter*> f2(nr, nullptr);
-    for (size_t j = 0; j < nr; ++j) {
-        HIPCHK(hipMemcpyAsync(w + o_q + j * (size_t) dim * 4, d_queries + (size_t) redo[j] * dim, (size_t) dim * 4,
-                              hipMemcpyDeviceToDevice, ctx->stream));
-        if (filters) f2[j] = filters[redo[j]];
+    if (n_rerun) *n_rerun = (int32_t) redo.size();
+    // flagged on the coarse planes: the fine planes next; flagged there (or no coarse tier involved): the exact kernels
+    for (int level = ctx->last_coarse ? 1 : 0; level >= 0 && !redo.empty(); --level) {
+        const size_t nr = redo.size(), nk = nr * (size_t) k;
+        // workspace: [queries | block | row | doc | dist | keys | counts] of the flagged queries
+        const size_t o_q = 0, o_blk = align_up(o_q + nr * (size_t) dim * 4, 256), o_row = align_up(o_blk + nk * 8, 256),
+                     o_doc = align_up(o_row + nk * 8, 256), o_dist = align_up(o_doc + nk * 4, 256),
+                     o_key = align_up(o_dist + nk * 4, 256), o_cnt = align_up(o_key + nk * 8, 256),
+                     total = align_up(o_cnt + nr * 4, 256);
+        if ((rc = ctx->d_redo.reserve(total))) return rc;
+        char* w = ctx->d_redo.as<char>();
+        std::vector<const vsr_filter*> f2(nr, nullptr);
+        for (size_t j = 0; j < nr; ++j) {
+            HIPCHK(hipMemcpyAsync(w + o_q + j * (size_t) dim * 4, d_queries + (size_t) redo[j] * dim, (size_t) dim * 4,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+            if (filters) f2[j] = filters[redo[j]];
+        }
+        rc = search_impl(ctx, c, nullptr, reinterpret_cast<const float*>(w + o_q), (int) nr, dim, k, metric, f2.data(),
+                         reinterpret_cast<int64_t*>(w + o_blk), reinterpret_cast<int32_t*>(w + o_doc),
+                         reinterpret_cast<int64_t*>(w + o_row), reinterpret_cast<float*>(w + o_dist),
+                         reinterpret_cast<int32_t*>(w + o_cnt), reinterpret_cast<uint64_t*>(w + o_key), level);
+        if (rc) return rc;
+        for (size_t j = 0; j < nr; ++j) {
+            const size_t src = j * (size_t) k, dst = (size_t) redo[j] * k;
+            auto patch = [&](void* to, const void* from, size_t bytes) {
+                return hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+            };
+            HIPCHK(patch(d_blk + dst, reinterpret_cast<int64_t*>(w + o_blk) + src, (size_t) k * 8));
+            if (d_row) HIPCHK(patch(d_row + dst, reinterpret_cast<int64_t*>(w + o_row) + src, (size_t) k * 8));
+            if (d_doc) HIPCHK(patch(d_doc + dst, reinterpret_cast<int32_t*>(w + o_doc) + src, (size_t) k * 4));
+            HIPCHK(patch(d_dist + dst, reinterpret_cast<float*>(w + o_dist) + src, (size_t) k * 4));
+            if (d_keys) HIPCHK(patch(d_keys + dst, reinterpret_cast<uint64_t*>(w + o_key) + src, (size_t) k * 8));
+            HIPCHK(patch(d_cnt + redo[j], reinterpret_cast<int32_t*>(w + o_cnt) + j, 4));
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(flags.data(), ctx->d_flags.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<int> still;
+        for (size_t j = 0; j < nr; ++j)
+            if (flags[j]) still.push_back(redo[j]);
+        // the exact path never flags; anything else is a library fault and must not be published
+        if (level == 0 && !still.empty())
+            return fail(VSR_ERR_HIP, "vsr_search_device_exact: query %d still flagged after the exact re-run", still[0]);
+        redo.swap(still);
     }
-    rc = search_impl(ctx, c, nullptr, reinterpret_cast<const float*>(w + o_q), (int) nr, dim, k, metric, f2.data(),
-                     reinterpret_cast<int64_t*>(w + o_blk), reinterpret_cast<int32_t*>(w + o_doc),
-                     reinterpret_cast<int64_t*>(w + o_row), reinterpret_cast<float*>(w + o_dist),
-                     reinterpret_cast<int32_t*>(w + o_cnt), reinterpret_cast<uint64_t*>(w + o_key), false);
-    if (rc) return rc;
-    for (size_t j = 0; j < nr; ++j) {
-        const size_t src = j * (size_t) k, dst = (size_t) redo[j] * k;
-        auto patch = [&](void* to, const void* from, size_t bytes) {
-            return hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, ctx->stream);
-        };
-        HIPCHK(patch(d_blk + dst, reinterpret_cast<int64_t*>(w + o_blk) + src, (size_t) k * 8));
-        if (d_row) HIPCHK(patch(d_row + dst, reinterpret_cast<int64_t*>(w + o_row) + src, (size_t) k * 8));
-        if (d_doc) HIPCHK(patch(d_doc + dst, reinterpret_cast<int32_t*>(w + o_doc) + src, (size_t) k * 4));
-        HIPCHK(patch(d_dist + dst, reinterpret_cast<float*>(w + o_dist) + src, (size_t) k * 4));
-        if (d_keys) HIPCHK(patch(d_keys + dst, reinterpret_cast<uint64_t*>(w + o_key) + src, (size_t) k * 8));
-        HIPCHK(patch(d_cnt + redo[j], reinterpret_cast<int32_t*>(w + o_cnt) + j, 4));
-    }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    // the exact path never flags; anything else is a library fault and must not be published
-    HIPCHK(hipMemcpy(flags.data(), ctx->d_flags.p, nr * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (size_t j = 0; j < nr; ++j)
-        if (flags[j]) return fail(VSR_ERR_HIP, "vsr_search_device_exact: query %d still flagged after the exact re-run", redo[j]);
-    if (n_rerun) *n_rerun = (int32_t) nr;
     return VSR_OK;
 }
 
@@ -2285,16 +2351,16 @@ static int host_search(vsr_corpus* c, const float* queries, int nq, int dim, int
     if ((rc = ctx->d_out.reserve(total))) return rc;
     if ((rc = ctx->h_out.reserve(total))) return rc;
     char* d = ctx->d_out.as<char>();
-    auto run = [&](const float* qs, int n, const vsr_filter* const* fs, bool screening) -> int {
+    auto run = [&](const float* qs, int n, const vsr_filter* const* fs, int level) -> int {
         int r = search_impl(ctx, c, qs, nullptr, n, dim, k, metric, fs, reinterpret_cast<int64_t*>(d + o_blk),
                             reinterpret_cast<int32_t*>(d + o_doc), reinterpret_cast<int64_t*>(d + o_row),
-                            reinterpret_cast<float*>(d + o_dist), reinterpret_cast<int32_t*>(d + o_cnt), nullptr, screening);
+                            reinterpret_cast<float*>(d + o_dist), reinterpret_cast<int32_t*>(d + o_cnt), nullptr, level);
         if (r) return r;
         HIPCHK(hipMemcpyAsync(ctx->h_out.p, d, total, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         return VSR_OK;
     };
-    if ((rc = run(queries, nq, filters, true))) return rc;
+    if ((rc = run(queries, nq, filters, 2))) return rc;
     char* h = ctx->h_out.as<char>();
     memcpy(out_blk, h + o_blk, nk * 8);
     if (out_row) memcpy(out_row, h + o_row, nk * 8);
@@ -2302,22 +2368,28 @@ static int host_search(vsr_corpus* c, const float* queries, int nq, int dim, int
     memcpy(out_dist, h + o_dist, nk * 4);
     memcpy(out_cnt, h + o_cnt, (size_t) nq * 4);
 
-    // K2 screening flags: re-run the (rare) flagged queries on the exact scan path
+    // screening flags: re-run the (rare) flagged queries one tier down -- coarse planes -> fine planes -> exact kernels
     std::vector<int32_t> flags((size_t) nq, 0);
     HIPCHK(hipMemcpy(flags.data(), ctx->d_flags.p, (size_t) nq * sizeof(int32_t), hipMemcpyDeviceToHost));
     std::vector<int> redo;
     for (int i = 0; i < nq; ++i)
         if (flags[(size_t) i]) redo.push_back(i);
-    if (!redo.empty()) {
-        ctx->flagged_seen += (int64_t) redo.size();
+    if (!redo.empty()) ctx->flagged_seen += (int64_t) redo.size();
+    for (int level = ctx->last_coarse ? 1 : 0; level >= 0 && !redo.empty(); --level) {
         std::vector<float> q2(redo.size() * (size_t) dim);
         std::vector<const vsr_filter*> f2(redo.size(), nullptr);
         for (size_t j = 0; j < redo.size(); ++j) {
             memcpy(&q2[j * (size_t) dim], queries + (size_t) redo[j] * dim, (size_t) dim * sizeof(float));
             if (filters) f2[j] = filters[redo[j]];
         }
-        if ((rc = run(q2.data(), (int) redo.size(), f2.data(), false))) return rc;
+        if ((rc = run(q2.data(), (int) redo.size(), f2.data(), level))) return rc;
+        HIPCHK(hipMemcpy(flags.data(), ctx->d_flags.p, redo.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<int> still;
         for (size_t j = 0; j < redo.size(); ++j) {
+            if (flags[j] && level > 0) {                      // unproven again: one more tier down
+                still.push_back(redo[j]);
+                continue;
+            }
             const size_t src = j * (size_t) k, dst = (size_t) redo[j] * k;
             memcpy(out_blk + dst, reinterpret_cast<int64_t*>(h + o_blk) + src, (size_t) k * 8);
             if (out_row) memcpy(out_row + dst, reinterpret_cast<int64_t*>(h + o_row) + src, (size_t) k * 8);
@@ -2325,6 +2397,7 @@ static int host_search(vsr_corpus* c, const float* queries, int nq, int dim, int
             memcpy(out_dist + dst, reinterpret_cast<float*>(h + o_dist) + src, (size_t) k * 4);
             out_cnt[redo[j]] = reinterpret_cast<int32_t*>(h + o_cnt)[j];
         }
+        redo.swap(still);
     }
     return VSR_OK;
 }
