@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r2", "traffic.json"),
                     help="PMC-derived HBM bytes per launch (tools/pmc_traffic.py) for roofline.traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wiki-rows", type=int, default=5_000_000, help="rows of the 768-d legs' corpus (0: skip the legs)")
+    ap.add_argument("--wiki-steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=20251121)
     return ap.parse_args()
 
@@ -92,6 +94,9 @@ MFMA_I8_PEAK_TOPS = 5000.0      # dense int8 MFMA peak, same guide (ops, reporte
 
 def kernel_layout(kernel, dim):
     """(bytes per row the launch reads, MFMA flops per (row, query) pair it issues, MFMA peak) for the launched kernel."""
+    if "K2g" in kernel:                  # coarse bf16 planes (hi only), rows padded to whole 64-element K-steps; one product
+        d_pad = -(-dim // 64) * 64
+        return d_pad * 2 + 4, 2 * d_pad, MFMA_BF16_PEAK_TF
     if "K2w" in kernel:
         if "PL=int8" in kernel:          # int8 planes (x - 128), 128 elements per row; one product, exact
             d_pad = -(-dim // 128) * 128
@@ -507,7 +512,10 @@ def main():
         "value": main_rec["value"], "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": ("int8 planes -> i32 (exact: bit-identical to the fp32 distances of vector.c)" if "PL=int8" in results[legs[0]]["kernel"]
+                  else "bf16 planes -> f32 (screen), f32 exact re-rank" if "K2" in results[legs[0]]["kernel"] else "f32"),
+        "data": "synthetic",
         "config": {"workload": f"SIFT10M-like {n}x{dim} fp32 L2 k={k}, tree RBAC 1000 users/100 roles, "
                                f"role-partition {legs[0]}, exact filtered top-k, {nq} queries/step ({nb} distinct batches)",
                    "rows": n, "dim": dim, "k": k, "queries_per_step": nq, "filter": legs[0],
@@ -580,6 +588,114 @@ def main():
         out["host_buffers"] = {"ms_per_step": round(th * 1e3, 4), "qps": round(nq / th, 1),
                                "one_query_per_call_ms": round(t1q * 1e3, 4),
                                "note": "vsr_search with host pointers (PCIe inclusive, synchronous); never `value`"}
+
+    # ---- 768-d legs (N = 1): BASELINE configs 3 / 5's row length, the path north_star names for MFMA ----
+    # wiki768_unfiltered: `--wiki-rows` x 768 unit rows (synthetic, Gaussian), 1000 queries per batch, cosine, no filter: one
+    #   filter part seen by every query = the batched-query x corpus GEMM (K2g: 256 x 256 tiles on the coarse bf16 planes)
+    # wiki768_rbac: the first 1M of those rows, tree RBAC (1000 users / 100 roles), every query under its user's role
+    #   pre-filter: ~100 permission classes, 10..330 queries each (K2w long rows, hi + mid planes)
+    # Each leg: event-timed main launch (roofline, bound "mfma": products issued / dense bf16 peak), wall time per batch,
+    # flagged queries (and the time with the tiered re-run when there are any), oracle spot check within 1e-4.
+    if world == 1 and sim_world <= 1 and args.wiki_rows > 0:
+        wd, wk = 768, 100
+        wn = int(args.wiki_rows)
+        tw = time.time()
+        xw = np.empty((wn, wd), dtype=np.float32)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(args.seed + 768)
+        for a in range(0, wn, 500_000):
+            t = torch.randn((min(500_000, wn - a), wd), generator=gen, device=dev, dtype=torch.float32)
+            t /= t.norm(dim=1, keepdim=True)
+            xw[a:a + t.shape[0]] = t.cpu().numpy()
+            del t
+        rw_ = np.arange(wn, dtype=np.int64)
+        blkw, docw = rw_ + 1, (rw_ // 10 + 1).astype(np.int32)
+        rngw = np.random.default_rng(args.seed + 769)
+        qw = xw[rngw.integers(0, wn, nq)] + 0.05 * rngw.standard_normal((nq, wd)).astype(np.float32)
+        d_qw = torch.from_numpy(qw).to(dev)
+        t_wgen = time.time() - tw
+        o_blk = torch.empty((nq, wk), dtype=torch.int64, device=dev)
+        o_doc = torch.empty((nq, wk), dtype=torch.int32, device=dev)
+        o_row = torch.empty((nq, wk), dtype=torch.int64, device=dev)
+        o_dist = torch.empty((nq, wk), dtype=torch.float32, device=dev)
+        o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+
+        def wiki_leg(cw, fl, label, workload, mask_of):
+            call = lambda: cw.search_device(ptr(d_qw), nq, wk, "cosine", fl, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist),
+                                            ptr(o_cnt), None, dim=wd)
+            for _ in range(2):
+                call()
+            torch.cuda.synchronize()
+            total0 = ctx.screening_check(0)[0]
+            ctx.profiling(2)
+            ctx.stats_reset()
+            t1 = time.perf_counter()
+            for _ in range(args.wiki_steps):
+                call()
+            torch.cuda.synchronize()
+            dtw = (time.perf_counter() - t1) / args.wiki_steps
+            stw = ctx.stats()
+            ctx.profiling(False)
+            kern = ctx.last_scan_kernel()
+            flagged_n = int((o_cnt < 0).sum().item())
+            assert ctx.screening_check(0)[0] - total0 == flagged_n * args.wiki_steps
+            roof = roofline_of(stw, wd, kern, 1)
+            rec = {"workload": workload, "value": round(nq / dtw, 1), "unit": "queries/s", "ms_per_step": round(dtw * 1e3, 4),
+                   "steps": args.wiki_steps, "dtype": "bf16 planes -> f32 accumulate (screen), f32 exact re-rank",
+                   "roofline": roof, "screening_flagged_queries": flagged_n}
+            if flagged_n:      # the serving form: search, wait, re-run what was flagged one tier down, patch
+                cw.search_device_exact(ptr(d_qw), nq, wk, "cosine", fl, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist), ptr(o_cnt),
+                                       None, dim=wd)
+                t2 = time.perf_counter()
+                for _ in range(args.wiki_steps):
+                    cw.search_device_exact(ptr(d_qw), nq, wk, "cosine", fl, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist),
+                                           ptr(o_cnt), None, dim=wd)
+                dte = (time.perf_counter() - t2) / args.wiki_steps
+                rec["with_tiered_rerun"] = {"ms_per_step": round(dte * 1e3, 4), "value": round(nq / dte, 1)}
+            else:
+                cw.search_device_exact(ptr(d_qw), nq, wk, "cosine", fl, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist), ptr(o_cnt),
+                                       None, dim=wd)
+            if not args.no_cpu_baseline:
+                from oracle.oracle import Oracle
+                orc_w = Oracle("pgflags")
+                rows_g, dist_g = o_row.cpu().numpy(), o_dist.cpu().numpy()
+                worst, overlap = 0.0, []
+                tcs = time.perf_counter()
+                for i in range(3):
+                    oidx, odist = orc_w.filtered_topk("cosine", cw._rows_host, qw[i], wk, cw._doc_host, cw._blk_host, mask_of(i))
+                    worst = max(worst, float(np.abs(dist_g[i, :len(odist)] - odist).max()))
+                    overlap.append(len(set(rows_g[i].tolist()) & set(oidx.tolist())))
+                rec["parity_spot_check"] = {"queries": 3, "max_abs_distance_error": worst, "tolerance": 1e-4,
+                                            "ids_in_common_of_k": overlap, "within_tolerance": bool(worst <= 1e-4 and min(overlap) >= wk - 1),
+                                            "oracle_qps_one_core": round(3 / (time.perf_counter() - tcs), 3)}
+            return rec
+
+        def host_view(cw, rows, doc_, blk_):                      # what the oracle checks against (host arrays, no copy)
+            cw._rows_host, cw._doc_host, cw._blk_host = rows, doc_, blk_
+            return cw
+
+        tl0 = time.time()
+        cw5 = host_view(ctx.load_corpus(xw, blkw, docw), xw, docw, blkw)
+        t_wload = time.time() - tl0
+        out["wiki768_unfiltered"] = wiki_leg(cw5, None, "unfiltered", f"{wn}x{wd} unit rows, cosine, k={wk}, {nq} unfiltered queries "
+                                             f"per batch (BASELINE config 5's shape on one GPU)", lambda i: None)
+        out["wiki768_unfiltered"]["setup_s"] = {"generate": round(t_wgen, 1), "load": round(t_wload, 1)}
+        out["wiki768_unfiltered"]["resident_bytes"] = {"fp32_rows": wn * wd * 4, "bf16_hi_mid_planes": wn * wd * 4, "bf16_coarse_planes": wn * wd * 2}
+        cw5.free()
+        n1 = min(wn, 1_000_000)
+        x1, blk1, doc1 = xw[:n1], blkw[:n1], docw[:n1]
+        cw1 = host_view(ctx.load_corpus(x1, blk1, doc1), x1, doc1, blk1)
+        rb1 = tree_rbac(num_users=1000, num_roles=100, num_docs=int(doc1.max()), seed=args.seed + 3)
+        cw1.load_rbac(rb1.user_roles, rb1.permissions)
+        users1 = rngw.integers(1, 1001, nq)
+        fl1 = cw1.pack_filters([cw1.filter_for_user(int(u), vsrbac.RANGES) for u in users1])
+        from oracle.oracle import Oracle as _Orc
+        _o = _Orc("pgflags")
+        out["wiki768_rbac"] = wiki_leg(cw1, fl1, "rbac", f"{n1}x{wd} unit rows, cosine, k={wk}, tree RBAC 1000 users / 100 roles, "
+                                       f"{nq} queries per batch under their users' role pre-filters (BASELINE config 3's shape)",
+                                       lambda i: _o.user_row_mask(int(users1[i]), rb1.user_roles, rb1.permissions, doc1))
+        cw1.free()
+        del xw
 
     # ---- CPU baseline (rank 0, N = 1): the oracle, pgvector's flags, one thread, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

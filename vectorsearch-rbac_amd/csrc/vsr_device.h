@@ -246,7 +246,7 @@ constexpr uint32_t MW_PEND = 256;                       // survivors a wave park
 inline size_t mfmaw_lds_bytes(bool int8 = false)
 {
     // two 64-row stage buffers (16 chunks per row; int8 planes: 8) + the row-mapping ring + per wave {value, row, column}[MW_PEND]
-    return (size_t) 2 * 64 * (int8 ? 8 : 16) * 16 + 8 * 64 * 8 + (size_t) 4 * MW_PEND * 12;
+    return (size_t) 2 * 64 * (int8 ? 8 : 16) * 16 + 8 * 64 * 8 + (size_t) 4 * MW_PEND * 12 + (int8 ? 8 * 64 * 4 : 0);   // (+ int8: threshold ring)
 }
 constexpr uint32_t GQ_CAP = 16384;                      // candidate keys per query (a filter this small needs no threshold at all)
 constexpr uint32_t GQ_SAMPLE_CAP = 4096;                // sampled minima per query kept for the threshold seed (more: dropped)

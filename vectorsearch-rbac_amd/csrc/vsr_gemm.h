@@ -86,6 +86,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
     // (all LDS lives in the one dynamic array: a second __shared__ object beside LDS-DMA staging can cost a vmcnt(0) per
     // fragment read, cdna_hip_programming.md "Three .s-level traps")
 
+    const bool sample_fine = SAMPLE && (grp.partial_begin & 1u);               // sample pass: one entry per lane, not per column
     const uint32_t cstride4 = p.cstride4;                                      // chunks per coarse plane row
     const uint32_t nks = cstride4 / GM_KC;                                     // K-steps per tile (>= 4)
     const uint32_t q_count = grp.q_count;
@@ -334,11 +335,14 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
                         }
                     }
                 if constexpr (SAMPLE) {
-                    uint64_t o = __shfl_xor(best, 16);
-                    best = o < best ? o : best;
-                    o = __shfl_xor(best, 32);
-                    best = o < best ? o : best;
-                    if (kq == 0 && best != KEY_EMPTY) {
+                    if (!sample_fine) {                                        // one minimum per column and wave-tile (128 rows)
+                        uint64_t o = __shfl_xor(best, 16);
+                        best = o < best ? o : best;
+                        o = __shfl_xor(best, 32);
+                        best = o < best ? o : best;
+                        if (kq != 0) best = KEY_EMPTY;
+                    }
+                    if (best != KEY_EMPTY) {
                         const uint32_t at = atomicAdd(p.qcnt + slot, 1u);
                         if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = best;
                     }

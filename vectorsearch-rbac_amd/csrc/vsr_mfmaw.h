@@ -155,6 +155,12 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
     uint32_t* pend_v = reinterpret_cast<uint32_t*>(pend) + (size_t) wave * MW_PEND;                       // key high word
     uint32_t* pend_r = reinterpret_cast<uint32_t*>(pend + 4 * MW_PEND * 4) + (size_t) wave * MW_PEND;     // row
     uint32_t* pend_c = reinterpret_cast<uint32_t*>(pend + 8 * MW_PEND * 4) + (size_t) wave * MW_PEND;     // query column 0..15
+    // int8 main launch with the mask epilogue: the candidate test runs on the integer accumulators.  |x - q|^2 <= tau  <=>
+    // 2 dot + (tau - |q|^2) >= |x|^2; the chain of query column j starts at c0 = ceil((tau - |q|^2) / 2) and a pair is a
+    // candidate when acc >= floor(|x|^2 / 2): ONE v_cmp per pair on the MFMA result as it stands (a superset of the exact
+    // test by at most one distance unit, which only costs a few more parked candidates; their keys are exact)
+    constexpr bool ITEST = I8 && EPI == 1 && !SAMPLE && METRIC == M_L2;
+    int32_t* rowthr = reinterpret_cast<int32_t*>(pend + 12 * MW_PEND * 4);     // [MW_RING][64] floor(|row|^2 / 2); no row: INT_MAX
 
     // ---- wave roles ----
     const uint32_t ngt = (q_count + MF_NQ - 1) / MF_NQ;                         // 16-query groups of this pass (1..4)
@@ -208,6 +214,9 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
     const bool open = my_tau == KEY_EMPTY;
     // screening limit: a value passes unless it is greater (NaN values pass; an open threshold admits everything)
     const float tau_lim = open ? __builtin_inff() : mono_to_float((uint32_t) (my_tau >> 32));
+    // (ITEST) what this lane's accumulators start from: ceil((tau - |q|^2) / 2); open threshold: everything passes, pad
+    // column: nothing does.  Distances, norms and thresholds of the int8 path are integers below 2^24.
+    const int32_t c0 = !qok ? -0x40000000 : open ? 0x3FFFFFFF : (((int32_t) tau_lim - (int32_t) my_qn) + 1) >> 1;
     // LONG rows: a pass holds up to 128 queries and wave w also owns query group w + 4 (the same A fragments feed both
     // groups' MFMAs: half the passes over the rows).  Its lanes carry a second set of per-query state.
     constexpr int NG = NGT;                                                    // query groups per wave (2: LONG only)
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
             rowidx[(it_ % MW_RING) * 64 + lane] = row;
             rownorm[(it_ % MW_RING) * 64 + lane] = row >= 0 ? nrm : __builtin_nanf("");   // NaN: an invalid slot's L2 value is NaN
                                                                                           // and fails every `<=` (fast path below)
+            if constexpr (ITEST) rowthr[(it_ % MW_RING) * 64 + lane] = row >= 0 ? ((int32_t) nrm) >> 1 : 0x7FFFFFFF;
         }
     };
     {
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
             for (int i = 0; i < NS; ++i) {
                 acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc8[i] = i32x4{0, 0, 0, 0};
+                acc8[i] = ITEST ? i32x4{c0, c0, c0, c0} : i32x4{0, 0, 0, 0};
             }
 
             auto do_stage = [&](auto sc) {
@@ -615,7 +625,7 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                 if constexpr (NCH > 1) do_stage(std::integral_constant<int, 1>{});
                 if constexpr (NCH > 2) do_stage(std::integral_constant<int, 2>{});
             }
-            if constexpr (I8) {
+            if constexpr (I8 && !ITEST) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
                     acc[i] = f32x4{(float) acc8[i][0], (float) acc8[i][1], (float) acc8[i][2], (float) acc8[i][3]};
@@ -646,12 +656,22 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
 #pragma unroll
                     for (int i = 0; i < NS; ++i) {
                         const int base = ((int) sub0 + i) * 16 + kq * 4;
-                        const float4 rn = *reinterpret_cast<const float4*>(&rnrm[base]);
-                        const float nx4[4] = {rn.x, rn.y, rn.z, rn.w};
+                        if constexpr (ITEST) {
+                            const int4 th = *reinterpret_cast<const int4*>(&rowthr[(it % MW_RING) * 64 + base]);
+                            const int32_t th4[4] = {th.x, th.y, th.z, th.w};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            m[i * 4 + r] = __ballot(screen_value<METRIC>(acc[i][r], nx4[r], my_qn) <= lim);
-                            any |= m[i * 4 + r];
+                            for (int r = 0; r < 4; ++r) {
+                                m[i * 4 + r] = __ballot(acc8[i][r] >= th4[r]);
+                                any |= m[i * 4 + r];
+                            }
+                        } else {
+                            const float4 rn = *reinterpret_cast<const float4*>(&rnrm[base]);
+                            const float nx4[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                m[i * 4 + r] = __ballot(screen_value<METRIC>(acc[i][r], nx4[r], my_qn) <= lim);
+                                any |= m[i * 4 + r];
+                            }
                         }
                     }
                     if (any) {
@@ -659,7 +679,10 @@ __global__ __launch_bounds__(MW_THREADS, mw_occ(NCH, PL, SAMPLE)) void mfma_wide
                         for (int j = 0; j < NS * 4; ++j)
                             if (m[j]) {                            // scalar test
                                 const int slot = ((int) sub0 + (j >> 2)) * 16 + kq * 4 + (j & 3);
-                                const float v = screen_value<METRIC>(acc[j >> 2][j & 3], rnrm[slot], my_qn);
+                                float dotf;
+                                if constexpr (ITEST) dotf = (float) (acc8[j >> 2][j & 3] - c0);
+                                else dotf = acc[j >> 2][j & 3];
+                                const float v = screen_value<METRIC>(dotf, rnrm[slot], my_qn);
                                 park_mask(m[j], (m[j] >> lane) & 1ull, mono_bits(v), (uint32_t) ridx[slot]);
                             }
                     }

@@ -1398,52 +1398,61 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         // kp + 6 sqrt(kp / f) + 4 / f (~600 at f = 1/16, kp = 200).  Dropping sample entries (minima, buffer
         // overflow) can only raise the m-th smallest, i.e. loosen the seed.  A query whose sample cannot reach rank m
         // gets an open threshold; that is only safe when all of its rows fit its candidate buffer (GQ_CAP).
-        plan.sample_stride = ctx->sample_stride;
-        const double ss = plan.sample_stride;
-        double frac = 1.0 / ss;
         const double tile_rows = plan.k2g ? 256.0 : 64.0;   // rows per workgroup tile of the kernel
-        for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
-            const ScanGroup& gs = plan.groups_s[gi];
-            const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / tile_rows);
-            const double per_block = std::ceil(t64 / gs.n_blocks);
-            const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
-            if (t64 > 0) frac = std::max(frac, sampled / t64);
-        }
-        const double lambda = (double) plan.keep * frac;
-        const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
-        plan.kp_frac = (float) lambda;
-        bool ok = seed_m <= GQ_SAMPLE_CAP / 4;
-        // fine passes: any query whose per-column minima (one per 64 rows of a sampled tile) would be fewer than 4 m
         static thread_local std::vector<double> est;
-        est.assign((size_t) nq, 0.0);
-        for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
-            ScanGroup& gs = plan.groups_s[gi];
-            bool fine = false;
-            for (uint32_t qi = 0; qi < gs.q_count; ++qi) {
-                const vsr_filter* f = fof(plan.q_slots[gs.q_begin + qi]);
-                const double allowed = f ? (double) f->allowed_rows : (double) c->n;
-                fine |= allowed / (64.0 * ss) < 4.0 * seed_m;
+        // K2g on a small corpus: its 256-row tiles make a thin sample; it is sampled more densely (stride 8, 4, 2) before
+        // the plan is given up.  (At the sizes it is built for -- millions of rows -- the first stride holds.)
+        bool ok = false;
+        for (uint32_t stride = ctx->sample_stride; !ok && stride >= 2; stride = plan.k2g ? stride / 2 : 0) {
+            plan.sample_stride = stride;
+            const double ss = stride;
+            double frac = 1.0 / ss;
+            for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
+                const ScanGroup& gs = plan.groups_s[gi];
+                const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / tile_rows);
+                const double per_block = std::ceil(t64 / gs.n_blocks);
+                const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
+                if (t64 > 0) frac = std::max(frac, sampled / t64);
             }
-            if (plan.k2g) fine = false;                            // K2g: one minimum per column and 128-row wave-tile
-            gs.partial_begin = fine ? 1u : 0u;                     // (K2w has no partial lists: the field carries the flag)
-            const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / tile_rows);
-            const double per_block = std::ceil(t64 / gs.n_blocks);
-            const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
-            const uint32_t ngt = (gs.q_count + 15) / 16;
-            const double waves_per_col = plan.k2g ? 2.0 : ngt == 1 ? 4.0 : ngt == 2 ? 2.0 : 1.0;     // row split (vsr_mfmaw.h)
-            const double entries_per_tile = waves_per_col * (fine ? 4.0 : 1.0);
-            const double rows_per_entry = tile_rows / entries_per_tile;
-            const double p_entry = std::min(1.0, gdens[gi] * rows_per_entry);      // a bitmap may leave an entry without rows
-            for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * entries_per_tile * p_entry;
+            const double lambda = (double) plan.keep * frac;
+            const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
+            plan.kp_frac = (float) lambda;
+            ok = seed_m <= GQ_SAMPLE_CAP / 4;
+            // fine passes: any query whose per-column minima (one per 64 rows of a sampled tile; K2g: one per 128) would be
+            // fewer than 4 m: one minimum per lane instead (4 x as many)
+            est.assign((size_t) nq, 0.0);
+            for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
+                ScanGroup& gs = plan.groups_s[gi];
+                bool fine = false;
+                for (uint32_t qi = 0; qi < gs.q_count; ++qi) {
+                    const vsr_filter* f = fof(plan.q_slots[gs.q_begin + qi]);
+                    const double allowed = f ? (double) f->allowed_rows : (double) c->n;
+                    fine |= allowed / ((plan.k2g ? 128.0 : 64.0) * ss) < 4.0 * seed_m;
+                }
+                gs.partial_begin = fine ? 1u : 0u;                     // (K2w / K2g have no partial lists: the field carries the flag)
+                const double t64 = std::ceil((double) gs.n_tiles * c->shape.rw / tile_rows);
+                const double per_block = std::ceil(t64 / gs.n_blocks);
+                const double sampled = std::min(t64, gs.n_blocks * std::ceil(per_block / ss));
+                const uint32_t ngt = (gs.q_count + 15) / 16;
+                const double waves_per_col = plan.k2g ? 2.0 : ngt == 1 ? 4.0 : ngt == 2 ? 2.0 : 1.0;     // row split (vsr_mfmaw.h)
+                const double entries_per_tile = waves_per_col * (fine ? 4.0 : 1.0);
+                const double rows_per_entry = tile_rows / entries_per_tile;
+                const double p_entry = std::min(1.0, gdens[gi] * rows_per_entry);      // a bitmap may leave an entry without rows
+                for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * entries_per_tile * p_entry;
+            }
+            for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
+                const vsr_filter* f = fof(q);
+                const int64_t allowed = f ? f->allowed_rows : c->n;
+                // the sample must be thick enough to reach rank m (with a margin where a bitmap makes the count random),
+                // unless all of the query's rows fit its buffer anyway
+                const bool exact_count = !f || f->allowed_rows == f->scanned_rows;
+                if (allowed > (int64_t) GQ_CAP && est[q] < (exact_count ? 1.25 * seed_m + 8.0 : 2.0 * seed_m)) ok = false;
+            }
         }
         plan.selq.resize((size_t) nq);
         for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
             const vsr_filter* f = fof(q);
             const int64_t allowed = f ? f->allowed_rows : c->n;
-            // the sample must be thick enough to reach rank m (with a margin where a bitmap makes the count random),
-            // unless all of the query's rows fit its buffer anyway
-            const bool exact_count = !f || f->allowed_rows == f->scanned_rows;
-            if (allowed > (int64_t) GQ_CAP && est[q] < (exact_count ? 1.25 * seed_m + 8.0 : 2.0 * seed_m)) ok = false;
             SelectQuery sq;
             sq.ids_begin = 0;
             sq.n_lists = 0;
