@@ -231,6 +231,14 @@ int vsr_hnsw_search(vsr_hnsw* index, const float* queries, int nq, int dim, int 
                     int64_t* out_block_ids, int32_t* out_doc_ids, int64_t* out_rows, float* out_dist, int32_t* out_counts,
                     int64_t* out_visited);
 
+/* same, queries (nq x dim floats, row stride dim) and outputs in device memory, enqueued on the corpus context's stream in
+ * ONE launch, no synchronisation.  On graphs beyond ~1M elements the visited set is a table in LDS sized by ef_search; a
+ * query that outgrows it reports count -1 (never a partial result): vsr_hnsw_search re-runs such queries itself. */
+int vsr_hnsw_search_device(vsr_hnsw* index, const float* d_queries, int nq, int dim, int k, int ef_search, int metric,
+                           const vsr_filter* const* filters,
+                           int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows, float* d_out_dist,
+                           int32_t* d_out_counts, int64_t* d_out_visited);
+
 /* opclass support functions for n vectors at once (host pointers): vector_norm (vector.c:756-769), l2_normalize
  * (vector.c:774-808; fails with "value out of range: overflow" like float_overflow_error) and
  * vector_spherical_distance (vector.c:692-711; unit vectors assumed, as IVFFlat's spherical k-means uses it) */

@@ -67,7 +67,7 @@ def test_gemm_path_is_exact_on_integer_rows(ctx, oracle, dim, nq, n):
     i.e. what is compared bit for bit with the oracle is K2g's own result, not a re-run's."""
     import vsrbac
     rng = np.random.default_rng(dim * 7 + nq)
-    k, n_cl, per_cl = 100, 40, 500
+    k, n_cl, per_cl = 100, 40, 330                    # per_cl < 4k: the survivor list reaches into the sea
     x = np.clip(np.rint(np.abs(rng.normal(0, 3, (n, dim)))), 0, 15).astype(np.float32)
     centres = np.clip(np.rint(np.abs(rng.normal(0, 3, (n_cl, dim)))), 0, 15).astype(np.float32)
 
@@ -91,8 +91,8 @@ def test_gemm_path_is_exact_on_integer_rows(ctx, oracle, dim, nq, n):
     assert (res.counts == k).all(), res.counts[res.counts != k][:8]
     for i in range(0, nq, max(1, nq // 10)):
         _expect_exact(oracle, res, i, "l2", x, q[i], k, doc, blk)
-    mask = (rng.random(n) < 0.4).astype(np.uint8)
-    mask[: n // 3] = 0                                                # a long masked stretch: whole tiles without a row
+    mask = (rng.random(n) < 0.6).astype(np.uint8)
+    mask[: n // 5] = 0                                                # a long masked stretch: whole tiles without a row
     for mode in (vsrbac.RANGES, vsrbac.BITMAP):
         f = corpus.filter_from_bytemask(mask, mode)
         res = _search_async(ctx, corpus, q, k, "l2", [f] * nq)

@@ -244,3 +244,63 @@ def test_index_caches_forget_freed_filters(ctx, oracle, hnsw20k):
     hnsw.free()
     ivf.free()
     corpus.free()
+
+
+def test_hnsw_limits_device_api_and_visited_forms(ctx, oracle, monkeypatch):
+    """pgvector's parameter ranges (m up to 100: neighbour lists longer than a wave; ef_search up to 5000), the device API
+    (one launch, no synchronisation, same answers), and the three forms of the visited set: the LDS bitmap (default on a
+    small graph), the LDS hash table (forced), its overflow -> global-bitmap re-run (forced with a tiny table)."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(123)
+    n, dim = 6000, 64
+    x = np.clip(np.rint(np.abs(rng.normal(0, 45, (n, dim)))), 0, 255).astype(np.float32)
+    blk = (np.arange(n) + 1).astype(np.int64)
+    doc = (np.arange(n) // 10 + 1).astype(np.int32)
+    oh = OracleHnsw(oracle, "l2", x, m=40, ef_construction=64, seed=11)     # 2m = 80 neighbours on layer 0
+    corpus = ctx.load_corpus(x, blk, doc)
+    gpu = corpus.load_hnsw(oh.export())
+    nq = 16
+    q = x[rng.integers(0, n, nq)] + rng.integers(-2, 3, (nq, dim)).astype(np.float32)
+
+    def check(ef, k):
+        res, vis = gpu.search(q, k, ef, "l2")
+        for i in range(nq):
+            rows_o, dist_o, _, nv = oh.search(q[i], ef)
+            m = min(k, rows_o.size)
+            assert res.counts[i] == m, (ef, i, res.counts[i], m)
+            np.testing.assert_array_equal(res.rows[i, :m], rows_o[:m])
+            np.testing.assert_array_equal(res.dist[i, :m], np.sqrt(dist_o[:m]).astype(np.float32))
+            assert vis[i] == nv, (ef, i, vis[i], nv)
+        return res
+
+    base = check(40, 40)
+    check(2000, 100)
+    check(5000, 100)                                                    # HNSW_MAX_EF_SEARCH: the whole graph is the beam
+    with pytest.raises(Exception):
+        gpu.search(q, 10, 5001, "l2")
+    # device API
+    dev = torch.device("cuda", 0)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    d_q = torch.from_numpy(q).to(dev)
+    o = {"blk": torch.empty((nq, 40), dtype=torch.int64, device=dev), "doc": torch.empty((nq, 40), dtype=torch.int32, device=dev),
+         "row": torch.empty((nq, 40), dtype=torch.int64, device=dev), "dist": torch.empty((nq, 40), dtype=torch.float32, device=dev),
+         "cnt": torch.empty((nq,), dtype=torch.int32, device=dev), "vis": torch.empty((nq,), dtype=torch.int64, device=dev)}
+    gpu.search_device(p(d_q), nq, 40, 40, "l2", None, p(o["blk"]), p(o["doc"]), p(o["row"]), p(o["dist"]), p(o["cnt"]), p(o["vis"]))
+    ctx.synchronize()
+    np.testing.assert_array_equal(o["row"].cpu().numpy(), base.rows)
+    np.testing.assert_array_equal(o["dist"].cpu().numpy(), base.dist)
+    np.testing.assert_array_equal(o["cnt"].cpu().numpy(), base.counts)
+    # visited forms
+    monkeypatch.setenv("VSR_HNSW_VISITED", "hash:8192")
+    check(40, 40)
+    monkeypatch.setenv("VSR_HNSW_VISITED", "hash:256")                 # overflows for every query: global-bitmap re-run
+    check(40, 40)
+    gpu.search_device(p(d_q), nq, 40, 40, "l2", None, p(o["blk"]), p(o["doc"]), p(o["row"]), p(o["dist"]), p(o["cnt"]), p(o["vis"]))
+    ctx.synchronize()
+    assert (o["cnt"].cpu().numpy() == -1).all()                         # the device API reports, it cannot re-run
+    monkeypatch.setenv("VSR_HNSW_VISITED", "global")
+    check(40, 40)
+    monkeypatch.delenv("VSR_HNSW_VISITED")
+    gpu.free()
+    corpus.free()

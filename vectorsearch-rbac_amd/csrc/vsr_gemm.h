@@ -40,11 +40,24 @@ namespace vsr {
 constexpr int GM_THREADS = 512;
 constexpr int GM_BM = 256;                 // rows per workgroup tile
 constexpr int GM_BN = 256;                 // query slots per pass
-constexpr int GM_KC = 8;                   // 16-byte chunks (8 bf16) per row and K-step: 64 elements, 128 bytes
-constexpr size_t GM_STAGE_U4 = (size_t) (GM_BM + GM_BN) * GM_KC;                  // uint4 per stage buffer (64 KB)
-inline size_t gemm_lds_bytes() { return 2 * GM_STAGE_U4 * 16 + 2 * GM_BM * 8 + GM_BN * 20 + 16; }
+constexpr int GM_KC = 4;                   // 16-byte chunks (8 bf16) per row and K-step: 32 elements, 64 bytes
+constexpr int GM_SLOTS = 4;                // stage ring: one slot being multiplied, three in flight
+constexpr size_t GM_STAGE_U4 = (size_t) (GM_BM + GM_BN) * GM_KC;                  // uint4 per stage slot (32 KB)
+// [stage ring | row ring: index, value | column constants, thresholds | mapping scratch: descriptor, bitmap word, norm | flag]
+inline size_t gemm_lds_bytes() { return GM_SLOTS * GM_STAGE_U4 * 16 + 2 * GM_BM * 8 + GM_BN * 20 + GM_BM * 20 + 16; }
 
 using lds_u4 = __attribute__((address_space(3))) uint4;
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
+
+// Every vector-memory operation of the tile loop is an LDS-DMA load (global_load_lds): the waves count them with
+// s_waitcnt vmcnt(N) and meet at a bare s_barrier, so that three stages stay in flight across barriers
+// (cdna_hip_programming.md, "Pipelining across barriers").  Per K-step a wave issues its four operand pieces; the row
+// mapping of the next tile (descriptor -> row -> permission word, |row|^2) rides in the same queue as 4-byte LDS-DMA
+// loads into a scratch area and is read back two K-steps later, when the counted wait has covered it.
+__device__ __forceinline__ void gm_wait_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <int METRIC, bool SAMPLE>
 __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanParams p)
@@ -72,23 +85,26 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
     const ScanGroup grp = p.groups[lo];
     const uint32_t local_block = p.block_map ? mapped_block : blockIdx.x - grp.block_begin;
     const auto g_tiles = as_global(grp.tiles);
-    const auto g_bitmap = as_global(grp.bitmap);
+    const auto g_bitmap = as_global(grp.bitmap ? grp.bitmap : p.ones);          // no bitmap: one all-ones word
+    const bool has_bitmap = grp.bitmap != nullptr;
     const auto g_norm2 = as_global(p.norm2);
     const auto g_rank = as_global(p.rank);
 
-    // LDS: [2 stage buffers: 256 row slots then 256 query slots, 8 chunks each | row ring: index, threshold | columns]
     uint4*   stage = reinterpret_cast<uint4*>(smem);
-    int32_t* rowidx = reinterpret_cast<int32_t*>(smem + 2 * GM_STAGE_U4 * 16);  // [2][256]
+    int32_t* rowidx = reinterpret_cast<int32_t*>(smem + GM_SLOTS * GM_STAGE_U4 * 16);  // [2][256]
     float*   rowval = reinterpret_cast<float*>(rowidx + 2 * GM_BM);            // [2][256] what a candidate's acc must reach (NaN: no row)
     float4*  colc = reinterpret_cast<float4*>(rowval + 2 * GM_BM);             // [256] {acc start, compare scale, |q|^2, slot bits}
     float*   collim = reinterpret_cast<float*>(colc + GM_BN);                   // [256] the threshold itself (generic epilogue)
-    uint32_t* s_open = reinterpret_cast<uint32_t*>(collim + GM_BN);             // any query column without a threshold
+    uint32_t* mapd = reinterpret_cast<uint32_t*>(collim + GM_BN);               // [2][256] tile descriptor words (x | y) of every row slot
+    uint32_t* mapb = mapd + 2 * GM_BM;                                          // [2][256] permission word (lo | hi)
+    float*    mapn = reinterpret_cast<float*>(mapb + 2 * GM_BM);                // [256] |row|^2
+    uint32_t* s_open = reinterpret_cast<uint32_t*>(mapn + GM_BM);               // any query column without a threshold
     // (all LDS lives in the one dynamic array: a second __shared__ object beside LDS-DMA staging can cost a vmcnt(0) per
     // fragment read, cdna_hip_programming.md "Three .s-level traps")
 
     const bool sample_fine = SAMPLE && (grp.partial_begin & 1u);               // sample pass: one entry per lane, not per column
     const uint32_t cstride4 = p.cstride4;                                      // chunks per coarse plane row
-    const uint32_t nks = cstride4 / GM_KC;                                     // K-steps per tile (>= 4)
+    const uint32_t nks = cstride4 / GM_KC;                                     // K-steps per tile (>= 8: d > 192)
     const uint32_t q_count = grp.q_count;
 
     // ---- query columns: thresholds folded into what the accumulators start from ----
@@ -129,84 +145,86 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
     if (n_it == 0) return;
     const uint32_t tile_last = grp.n_tiles - 1u;
     const uint32_t last_row = p.n_rows - 1u;
+    const uint32_t mslot = (uint32_t) tid & (GM_BM - 1);                        // row slot this thread maps (threads 0..255)
 
-    // row mapping of tile it_ in three steps (threads 0..255, slot = tid); each step consumes the previous step's loads
-    uint2    m_desc = make_uint2(0u, 0u);
-    int32_t  m_row = -1;
-    uint64_t m_bw = ~0ull;
-    float    m_nrm = 0.0f;
-    auto map_fetch = [&](uint32_t it_) {
-        const uint32_t t = t0 + it_ * ss * tps + (uint32_t) (tid & (GM_BM - 1)) / rw;
-        const bool ok = it_ < n_it && t < t1;
+    // what row slot `mslot` of tile it_ is, from its list-tile descriptor d: (row or -1, clamped row)
+    auto list_tile_of = [&](uint32_t it_) -> uint32_t { return t0 + it_ * ss * tps + mslot / rw; };
+    auto slot_row = [&](uint32_t it_, uint2 d, uint32_t& rc) -> int32_t {
+        const uint32_t t = list_tile_of(it_);
+        const bool tile_ok = it_ < n_it && t < t1;
+        const uint32_t r = mslot % rw;
+        const uint32_t rr = d.x + r;
+        const bool ok = tile_ok && r < d.y && rr <= last_row;
+        rc = ok ? rr : 0u;
+        return ok ? (int32_t) rr : -1;
+    };
+    auto commit = [&](uint32_t it_, int32_t row, uint64_t bw, float nrm) {
+        if (row >= 0 && !((bw >> ((uint32_t) row & 63u)) & 1ull)) row = -1;
+        float v;
+        if (generic) v = nrm;                                                  // generic epilogue: |row|^2 itself
+        else if constexpr (METRIC == M_L2) v = 0.5f * nrm;
+        else if constexpr (METRIC == M_IP) v = 0.0f;
+        else v = sqrtf(nrm);
+        rowidx[(it_ & 1u) * GM_BM + mslot] = row;
+        rowval[(it_ & 1u) * GM_BM + mslot] = row >= 0 ? v : __builtin_nanf("");
+    };
+    // tile 0 is mapped with plain loads (nothing is in flight yet); later tiles through the LDS-DMA chain in the loop
+    if (tid < GM_BM) {
+        const uint32_t t = list_tile_of(0);
         const uint2 d = load_tile(g_tiles, t < tile_last ? t : tile_last);
-        m_desc = make_uint2(ok ? d.x : 0u, ok ? d.y : 0u);
-    };
-    auto map_rows = [&]() {
-        const uint32_t r = (uint32_t) (tid & (GM_BM - 1)) % rw;
-        const uint32_t rr = m_desc.x + r;
-        const bool ok = r < m_desc.y && rr <= last_row;
-        const uint32_t rc = ok ? rr : 0u;
-        m_row = ok ? (int32_t) rr : -1;
-        m_bw = g_bitmap ? g_bitmap[rc >> 6] : ~0ull;
-        m_nrm = g_norm2[rc];
-    };
-    auto map_commit = [&](uint32_t it_) {
-        if (tid < GM_BM) {
-            int32_t row = m_row;
-            if (row >= 0 && !((m_bw >> ((uint32_t) row & 63u)) & 1ull)) row = -1;
-            float v;
-            if (SAMPLE || generic) v = m_nrm;                                  // generic epilogue: |row|^2 itself
-            else if constexpr (METRIC == M_L2) v = 0.5f * m_nrm;
-            else if constexpr (METRIC == M_IP) v = 0.0f;
-            else v = sqrtf(m_nrm);
-            rowidx[(it_ & 1u) * GM_BM + tid] = row;
-            rowval[(it_ & 1u) * GM_BM + tid] = row >= 0 ? v : __builtin_nanf("");
-        }
-    };
-    map_fetch(0);
-    map_rows();
-    map_commit(0);
-    map_fetch(1);
+        uint32_t rc;
+        const int32_t row = slot_row(0, d, rc);
+        const uint64_t bw = g_bitmap[has_bitmap ? rc >> 6 : 0u];
+        commit(0, row, bw, g_norm2[rc]);
+    }
     __syncthreads();
 
-    // ---- operand staging: wave w issues the four 1-KB pieces 4w .. 4w+3 of the row half and of the query half ----
-    // piece = 8 slots x 128 bytes; lane -> (slot = 8 piece + (lane >> 3), LDS chunk = lane & 7) fetches source chunk
-    // (lane & 7) ^ (slot & 7) of that slot's plane row, so that LDS chunk c of slot s holds source chunk c ^ (s & 7)
-    const uint32_t l_slot = (uint32_t) lane >> 3;
-    const uint32_t l_src = ((uint32_t) lane & 7u) ^ l_slot;                     // slot & 7 == l_slot (pieces start at multiples of 8)
-    const uint4* a_src[4];
-    const uint4* b_src[4];
+    // ---- operand staging: wave w issues the 1-KB pieces 2w, 2w+1 of the row half and of the query half of a stage ----
+    // piece = 16 slots x 64 bytes; lane -> (slot = 16 piece + (lane >> 2), LDS chunk = lane & 3) fetches source chunk
+    // (lane & 3) ^ sw(slot) of that slot's plane row, sw(slot) = (-(slot >> 2)) & 3: with it the 16-byte fragment reads of
+    // a 16-lane group (4 banks each) cover all 64 banks exactly once
+    const uint32_t l_slot = (uint32_t) lane >> 2;
+    const uint32_t l_src = ((uint32_t) lane & 3u) ^ ((0u - (l_slot >> 2)) & 3u);   // (slot >> 2) & 3 == (l_slot >> 2) & 3: pieces start at multiples of 16
+    const uint4* a_cur[2];
+    const uint4* a_nxt[2];
+    const uint4* b_src[2];
 #pragma unroll
-    for (int pc = 0; pc < 4; ++pc) {
-        const uint32_t qs = (uint32_t) (wave * 4 + pc) * 8u + l_slot;
+    for (int pc = 0; pc < 2; ++pc) {
+        const uint32_t qs = (uint32_t) (wave * 2 + pc) * 16u + l_slot;
         const uint32_t slot = p.q_slots[grp.q_begin + (qs < q_count ? qs : 0u)];
         b_src[pc] = p.q_scr_c + (size_t) slot * cstride4 + l_src;
     }
-    auto set_rows = [&](uint32_t it_) {
+    auto rows_of = [&](uint32_t it_, const uint4* (&dst)[2]) {
         const int32_t* ridx = rowidx + (it_ & 1u) * GM_BM;
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) {
-            const int32_t r = ridx[(wave * 4 + pc) * 8 + (int) l_slot];
-            a_src[pc] = p.scr_c + (size_t) (uint32_t) (r < 0 ? 0 : r) * cstride4 + l_src;
+        for (int pc = 0; pc < 2; ++pc) {
+            const int32_t r = ridx[(wave * 2 + pc) * 16 + (int) l_slot];
+            dst[pc] = p.scr_c + (size_t) (uint32_t) (r < 0 ? 0 : r) * cstride4 + l_src;
         }
     };
-    auto issue = [&](uint32_t ks, int buf) {
-        lds_u4* dst = (lds_u4*) (stage + (size_t) buf * GM_STAGE_U4);
+    auto issue = [&](const uint4* (&a)[2], uint32_t ks, uint32_t slot_) {
+        lds_u4* dst = (lds_u4*) (stage + (size_t) slot_ * GM_STAGE_U4);
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) {
-            __builtin_amdgcn_global_load_lds(as_global(a_src[pc] + ks * GM_KC), dst + (wave * 4 + pc) * 64, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(as_global(b_src[pc] + ks * GM_KC), dst + GM_BM * GM_KC + (wave * 4 + pc) * 64, 16, 0, 0);
+        for (int pc = 0; pc < 2; ++pc) {
+            __builtin_amdgcn_global_load_lds(as_global(a[pc] + ks * GM_KC), dst + (wave * 2 + pc) * 64, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(as_global(b_src[pc] + ks * GM_KC), dst + GM_BM * GM_KC + (wave * 2 + pc) * 64, 16, 0, 0);
         }
     };
 
     // MFMA lane roles (16x16x32): A lane = (row li, k-octet kq); B / result lane = (k-octet kq | row quad kq, query jq)
     const int li = lane & 15;
     const int kq = lane >> 4;
+    const uint32_t frag_off = (uint32_t) li * GM_KC + ((uint32_t) kq ^ ((0u - ((uint32_t) li >> 2)) & 3u));   // + 64 per 16-slot block
     f32x4 acc[8][4];
 
-    set_rows(0);
-    issue(0, 0);
-    int buf = 0;
+    rows_of(0, a_cur);
+    a_nxt[0] = a_cur[0];
+    a_nxt[1] = a_cur[1];
+    // stages are numbered through all tiles: g = it * nks + ks lives in ring slot g & 3; three are in flight
+    issue(a_cur, 0, 0);
+    issue(a_cur, 1, 1);
+    issue(a_cur, 2, 2);
+    uint32_t g = 0;
     for (uint32_t it = 0; it < n_it; ++it) {
         // accumulators start from the folded thresholds of their query columns
 #pragma unroll
@@ -215,41 +233,52 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i][j] = f32x4{s, s, s, s};
         }
-        for (uint32_t ks = 0; ks < nks; ++ks) {
-            __syncthreads();                                                   // stage `buf` has landed everywhere; `buf ^ 1` is free
-            // row mapping of the next tile, one step per K-step (their loads were complete at the barrier above)
-            if (ks == 0) map_rows();
-            else if (ks == 1) { map_commit(it + 1); map_fetch(it + 2); }
-            const bool last = ks + 1 == nks;
-            if (last) set_rows(it + 1);                                        // (committed two barriers ago)
-            issue(last ? 0u : ks + 1, buf ^ 1);                                // past the last tile: row 0, never used
-            const uint4* sa = stage + (size_t) buf * GM_STAGE_U4 + (size_t) (wm * 128) * GM_KC;
-            const uint4* sb = stage + (size_t) buf * GM_STAGE_U4 + (size_t) (GM_BM + wn * 64) * GM_KC;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                bf16x8 bfr[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = j * 16 + li;
-                    bfr[j] = __builtin_bit_cast(bf16x8, sb[q * GM_KC + ((kb * 4 + kq) ^ (q & 7))]);
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    bf16x8 afr[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = (h * 4 + i) * 16 + li;
-                        afr[i] = __builtin_bit_cast(bf16x8, sa[r * GM_KC + ((kb * 4 + kq) ^ (r & 7))]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+        for (uint32_t ks = 0; ks < nks; ++ks, ++g) {
+            gm_wait_barrier();                               // stage g has landed in every wave's share; slot (g + 3) & 3 is free
+            // ---- row mapping of tile it + 1 (threads 0..255), spread over K-steps 0 / 2 / 4 ----
+            if (tid < GM_BM) {
+                if (ks == 0) {
+                    const uint32_t t = list_tile_of(it + 1);
+                    const gptr<uint32_t> src = (gptr<uint32_t>) (g_tiles + (t < tile_last ? t : tile_last));
+                    __builtin_amdgcn_global_load_lds(src, (lds_u32*) mapd + wave * 64, 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(src + 1, (lds_u32*) mapd + GM_BM + wave * 64, 4, 0, 0);
+                } else if (ks == 2) {
+                    uint32_t rc;
+                    (void) slot_row(it + 1, make_uint2(mapd[mslot], mapd[GM_BM + mslot]), rc);
+                    const gptr<uint32_t> bsrc = (gptr<uint32_t>) (g_bitmap + (has_bitmap ? rc >> 6 : 0u));
+                    __builtin_amdgcn_global_load_lds(bsrc, (lds_u32*) mapb + wave * 64, 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(bsrc + 1, (lds_u32*) mapb + GM_BM + wave * 64, 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr<uint32_t>) (g_norm2 + rc), (lds_u32*) mapn + wave * 64, 4, 0, 0);
+                } else if (ks == 4) {
+                    uint32_t rc;
+                    const int32_t row = slot_row(it + 1, make_uint2(mapd[mslot], mapd[GM_BM + mslot]), rc);
+                    commit(it + 1, row, ((uint64_t) mapb[GM_BM + mslot] << 32) | mapb[mslot], mapn[mslot]);
                 }
             }
-            buf ^= 1;
+            // ---- three stages ahead: stage g + 3 (of the next tile from K-step nks - 3 on) ----
+            const uint32_t ks3 = ks + 3 < nks ? ks + 3 : ks + 3 - nks;
+            if (ks + 3 == nks) rows_of(it + 1, a_nxt);       // (committed at K-step 4 <= nks - 4, a barrier ago at least)
+            if (ks + 3 < nks) issue(a_cur, ks3, (g + 3) & 3u);
+            else issue(a_nxt, ks3, (g + 3) & 3u);             // past the last tile: row 0, never used
+            const uint4* sa = stage + (size_t) (g & 3u) * GM_STAGE_U4 + (size_t) (wm * 128) * GM_KC + frag_off;
+            const uint4* sb = stage + (size_t) (g & 3u) * GM_STAGE_U4 + (size_t) (GM_BM + wn * 64) * GM_KC + frag_off;
+            bf16x8 bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8, sb[j * 64]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 afr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) afr[i] = __builtin_bit_cast(bf16x8, sa[(h * 4 + i) * 64]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+            }
         }
+        a_cur[0] = a_nxt[0];
+        a_cur[1] = a_nxt[1];
 
         // ---- epilogue: acc[i][j][r] belongs to row slot wm * 128 + i * 16 + kq * 4 + r and query column wn * 64 + j * 16 + li ----
         const int32_t* ridx = rowidx + (it & 1u) * GM_BM + wm * 128;
@@ -350,6 +379,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
             }
         }
     }
+    // the three stages still in flight write LDS: they must have landed before the workgroup gives its LDS back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int METRIC>
@@ -362,7 +393,7 @@ hipError_t launch_gemm_metric(const ScanParams& p, uint32_t n_blocks, hipStream_
         hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(GM_THREADS), lds, s, p);
         return hipGetLastError();
     };
-    if (p.cstride4 < 4 * GM_KC || p.cstride4 % GM_KC != 0 || GM_BM % p.rw != 0) return hipErrorInvalidValue;
+    if (p.cstride4 < 8 * GM_KC || p.cstride4 % GM_KC != 0 || GM_BM % p.rw != 0 || !p.ones) return hipErrorInvalidValue;
     return p.sample_stride > 1 ? launch(gemm_screen_kernel<METRIC, true>) : launch(gemm_screen_kernel<METRIC, false>);
 }
 

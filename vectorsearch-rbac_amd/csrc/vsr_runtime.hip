@@ -2842,7 +2842,8 @@ struct vsr_hnsw {
             *d_tid_count = nullptr, *d_tids = nullptr;
     std::map<uint64_t, uint64_t*> bitmaps;           // filters (by vsr_filter::id) without a full bitmap of their own, as one
     DevBuf d_q, d_vis, d_out, d_bm;
-    PinBuf h_out;
+    PinBuf h_out, h_bm;
+    int last_mode = -1;                              // visited form of the last launch (HnswVisited)
 };
 
 extern "C" int vsr_hnsw_free(vsr_hnsw* h)
@@ -2861,7 +2862,6 @@ extern "C" int vsr_hnsw_free(vsr_hnsw* h)
         if (p) (void) hipFree(p);
     for (auto& kv : h->bitmaps)
         if (kv.second) (void) hipFree(kv.second);
-    h->d_q.release(); h->d_vis.release(); h->d_out.release(); h->d_bm.release(); h->h_out.release();
     delete h;
     return VSR_OK;
 }
@@ -2873,7 +2873,8 @@ extern "C" int vsr_hnsw_load(vsr_corpus* c, int m, int32_t n_elem, int32_t entry
     if (!c || !out) return fail(VSR_ERR_INVALID, "vsr_hnsw_load: NULL argument");
     *out = nullptr;
     if (c->base) return fail(VSR_ERR_INVALID, "vsr_hnsw_load: the corpus is a view");
-    if (m < 2 || m > 32) return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_load: m must be between 2 and 32 (got %d)", m);   // 2m ids per wave
+    if (m < 2 || m > 100)        /* reloption m: 2 .. HNSW_MAX_M (hnsw.h:36-40) */
+        return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_load: m must be between 2 and 100 (got %d)", m);
     if (n_elem < 0 || (n_elem > 0 && (!level || !nbr0 || !tid_count || !tids || !up_slot)) || max_level < 1 || n_upper < 0 ||
         (n_upper > 0 && !up_nbr) || entry >= n_elem)
         return fail(VSR_ERR_INVALID, "vsr_hnsw_load: bad graph arrays");
@@ -2972,94 +2973,199 @@ static int hnsw_filter_bitmap(vsr_hnsw* h, const vsr_filter* f, const uint64_t**
     return VSR_OK;
 }
 
+// One launch over queries resident in device memory (rows of q_stride floats), results into device arrays; bitmaps: one
+// device pointer per query (d_bm, may be nullptr).  status_out / visited_out are optional device arrays.
+static int hnsw_launch(vsr_hnsw* h, vsr_ctx* ctx, const float* d_q, uint32_t q_stride, int nq, int k, int ef, int metric,
+                       const uint64_t* const* d_bm, bool force_global, int64_t* d_blk, int32_t* d_doc, int64_t* d_row, float* d_dist,
+                       int32_t* d_cnt, int64_t* d_vis, int32_t* d_status)
+{
+    vsr_corpus* c = h->corpus;
+    HnswParams p{};
+    p.rows = c->d_rows;
+    p.stride4 = c->stride4;
+    p.metric = metric;
+    p.queries = d_q;
+    p.q_stride = q_stride;
+    p.dim = (uint32_t) c->dim;
+    p.nq = (uint32_t) nq;
+    p.n_elem = (uint32_t) h->n_elem;
+    p.entry = h->entry;
+    p.entry_level = h->entry_level;
+    p.m = (uint32_t) h->m;
+    p.max_level = (uint32_t) h->max_level;
+    p.elem_row = h->d_elem_row;
+    p.nbr0 = h->d_nbr0;
+    p.up_slot = h->d_up_slot;
+    p.up_nbr = h->d_up_nbr;
+    p.level = h->d_level;
+    p.tid_count = h->d_tid_count;
+    p.tids = h->d_tids;
+    p.bitmaps = d_bm;
+    p.ef = (uint32_t) ef;
+    p.k = (uint32_t) k;
+    p.caps = (uint32_t) (2 * ef + 2 * h->m + 64);
+    if (!hnsw_plan(p, force_global)) {                      // S does not fit beside anything: a shorter tail behind W
+        p.caps = (uint32_t) (ef + 2 * h->m + 64);
+        if (!hnsw_plan(p, force_global)) return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_search: ef_search = %d does not fit the LDS", ef);
+    }
+    // development / tests: VSR_HNSW_VISITED=hash[:slots] forces the LDS hash table (with `slots` entries, a power of two) on a
+    // graph small enough for the LDS bitmap, so that the table and its overflow re-run can be exercised on small graphs
+    if (!force_global) {
+        const char* env = getenv("VSR_HNSW_VISITED");
+        if (env && !strncmp(env, "hash", 4)) {
+            uint32_t slots = env[4] == ':' ? (uint32_t) atoi(env + 5) : 4096u;
+            while (slots & (slots - 1)) slots &= slots - 1;
+            slots = std::max(64u, slots);
+            const size_t fixed = hnsw_lds_fixed(p.caps);
+            if (fixed + (size_t) slots * 4 <= HN_LDS_BUDGET) {
+                p.vis_mode = VIS_LDS_HASH;
+                p.vis_words = slots;
+                p.lds_per_query = (uint32_t) ((fixed + (size_t) slots * 4 + 15) & ~(size_t) 15);
+                p.qpb = 1;
+            }
+        } else if (env && !strcmp(env, "global")) {
+            (void) hnsw_plan(p, true);
+        }
+    }
+    if (p.vis_mode == VIS_GLOBAL) {
+        int rc = h->d_vis.reserve((size_t) nq * p.vis_words * 4);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(h->d_vis.p, 0, (size_t) nq * p.vis_words * 4, ctx->stream));
+        p.visited = h->d_vis.as<uint32_t>();
+    }
+    p.block_ids = c->d_block;
+    p.doc_ids = c->d_doc;
+    p.orig_rows = c->d_orig;
+    p.out_block = d_blk;
+    p.out_doc = d_doc;
+    p.out_row = d_row;
+    p.out_dist = d_dist;
+    p.out_count = d_cnt;
+    p.out_visited = d_vis;
+    p.out_status = d_status;
+    p.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;
+    HIPCHK(launch_hnsw_search(p, ctx->stream));
+    h->last_mode = p.vis_mode;
+    return VSR_OK;
+}
+
+static int hnsw_check(vsr_hnsw* h, const void* queries, int nq, int dim, int k, int ef, int metric, const vsr_filter* const* filters,
+                      const char* who)
+{
+    if (!h) return fail(VSR_ERR_INVALID, "%s: index is NULL", who);
+    int rc = check_search_args(h->corpus, queries, nq, dim, k, metric, filters, who);
+    if (rc) return rc;
+    if (metric == VSR_METRIC_L1) return fail(VSR_ERR_UNSUPPORTED, "%s: L1 graphs are not supported", who);
+    if (ef < 1 || ef > 5000)      /* hnsw.ef_search: 1 .. HNSW_MAX_EF_SEARCH (hnsw.c:86-89, hnsw.h:44) */
+        return fail(VSR_ERR_INVALID, "%s: ef_search must be between 1 and 5000 (got %d)", who, ef);
+    return VSR_OK;
+}
+
+// per-query permission bitmaps as a device array of pointers (nullptr entries: no filter); any_filter = false: none at all
+static int hnsw_bitmaps(vsr_hnsw* h, vsr_ctx* ctx, const vsr_filter* const* filters, int q0, int n, bool& any_filter)
+{
+    any_filter = false;
+    std::vector<const uint64_t*> bms((size_t) n, nullptr);
+    int rc;
+    for (int i = 0; i < n; ++i)
+        if (filters && filters[q0 + i]) {
+            if ((rc = hnsw_filter_bitmap(h, filters[q0 + i], &bms[(size_t) i]))) return rc;
+            any_filter = true;
+        }
+    if (!any_filter) return VSR_OK;
+    if ((rc = h->d_bm.reserve((size_t) n * sizeof(uint64_t*)))) return rc;
+    if ((rc = h->h_bm.reserve((size_t) n * sizeof(uint64_t*)))) return rc;
+    memcpy(h->h_bm.p, bms.data(), (size_t) n * sizeof(uint64_t*));
+    HIPCHK(hipMemcpyAsync(h->d_bm.p, h->h_bm.p, (size_t) n * sizeof(uint64_t*), hipMemcpyHostToDevice, ctx->stream));
+    return VSR_OK;
+}
+
+extern "C" int vsr_hnsw_search_device(vsr_hnsw* h, const float* d_queries, int nq, int dim, int k, int ef, int metric,
+                                      const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row,
+                                      float* d_dist, int32_t* d_cnt, int64_t* d_visited)
+{
+    int rc = hnsw_check(h, d_queries, nq, dim, k, ef, metric, filters, "vsr_hnsw_search_device");
+    if (rc) return rc;
+    if (nq == 0) return VSR_OK;
+    if (!d_blk || !d_dist || !d_cnt) return fail(VSR_ERR_INVALID, "vsr_hnsw_search_device: output is NULL");
+    vsr_ctx* ctx = h->corpus->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!d_doc) {
+        if ((rc = h->d_out.reserve((size_t) nq * k * sizeof(int32_t)))) return rc;
+        d_doc = h->d_out.as<int32_t>();
+    }
+    bool any_filter = false;
+    if (h->h_bm.p) HIPCHK(hipStreamSynchronize(ctx->stream));            // the pinned pointer block of the previous call
+    if ((rc = hnsw_bitmaps(h, ctx, filters, 0, nq, any_filter))) return rc;
+    return hnsw_launch(h, ctx, d_queries, (uint32_t) dim, nq, k, ef, metric, any_filter ? h->d_bm.as<const uint64_t*>() : nullptr, false,
+                       d_blk, d_doc, d_row, d_dist, d_cnt, d_visited, nullptr);
+}
+
 extern "C" int vsr_hnsw_search(vsr_hnsw* h, const float* queries, int nq, int dim, int k, int ef, int metric,
                                const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
                                float* out_dist, int32_t* out_cnt, int64_t* out_visited)
 {
-    if (!h) return fail(VSR_ERR_INVALID, "vsr_hnsw_search: index is NULL");
-    vsr_corpus* c = h->corpus;
-    int rc = check_search_args(c, queries, nq, dim, k, metric, filters, "vsr_hnsw_search");
+    int rc = hnsw_check(h, queries, nq, dim, k, ef, metric, filters, "vsr_hnsw_search");
     if (rc) return rc;
-    if (metric == VSR_METRIC_L1) return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_search: L1 graphs are not supported");
-    if (ef < 1 || ef > 1000) return fail(VSR_ERR_INVALID, "vsr_hnsw_search: ef_search must be between 1 and 1000 (got %d)", ef);   /* hnsw.c:86-89 */
     if (nq == 0) return VSR_OK;
     if (!out_blk || !out_dist || !out_cnt) return fail(VSR_ERR_INVALID, "vsr_hnsw_search: output is NULL");
+    vsr_corpus* c = h->corpus;
     vsr_ctx* ctx = c->ctx;
     HIPCHK(hipSetDevice(ctx->device));
-    const size_t qfloats = (size_t) c->stride4 * 4;
-    const uint32_t vwords = (uint32_t) ((std::max(h->n_elem, 1) + 31) / 32);
-    const int chunk = (int) std::max<size_t>(1, std::min<size_t>((size_t) nq, ((size_t) 256 << 20) / ((size_t) vwords * 4)));
-    const size_t nk = (size_t) chunk * k;
+    // one launch for the whole call; results come back in one copy.  Queries whose LDS visited table overflowed (big graphs
+    // only) are re-run with the global bitmap
+    const size_t nk = (size_t) nq * k;
     const size_t o_blk = 0, o_row = align_up(o_blk + nk * 8, 256), o_doc = align_up(o_row + nk * 8, 256),
                  o_dist = align_up(o_doc + nk * 4, 256), o_cnt = align_up(o_dist + nk * 4, 256),
-                 o_vis = align_up(o_cnt + (size_t) chunk * 4, 256), total = align_up(o_vis + (size_t) chunk * 8, 256);
-    if ((rc = h->d_q.reserve((size_t) chunk * qfloats * sizeof(float)))) return rc;
-    if ((rc = h->d_vis.reserve((size_t) chunk * vwords * 4))) return rc;
+                 o_vis = align_up(o_cnt + (size_t) nq * 4, 256), o_st = align_up(o_vis + (size_t) nq * 8, 256),
+                 total = align_up(o_st + (size_t) nq * 4, 256);
+    if ((rc = h->d_q.reserve((size_t) nq * dim * sizeof(float)))) return rc;
     if ((rc = h->d_out.reserve(total))) return rc;
     if ((rc = h->h_out.reserve(total))) return rc;
-    if ((rc = h->d_bm.reserve((size_t) chunk * sizeof(uint64_t*)))) return rc;
-    std::vector<float> qpad((size_t) chunk * qfloats);
-    std::vector<const uint64_t*> bms((size_t) chunk);
-    for (int q0 = 0; q0 < nq; q0 += chunk) {
-        const int n = std::min(chunk, nq - q0);
-        std::fill(qpad.begin(), qpad.end(), 0.0f);
+    char* d = h->d_out.as<char>();
+    char* hh = h->h_out.as<char>();
+    auto run = [&](const float* qs, int n, const vsr_filter* const* fs, bool force_global) -> int {
         bool any_filter = false;
-        for (int i = 0; i < n; ++i) {
-            memcpy(&qpad[(size_t) i * qfloats], queries + (size_t) (q0 + i) * dim, (size_t) dim * sizeof(float));
-            bms[(size_t) i] = nullptr;
-            if (filters && filters[q0 + i]) {
-                if ((rc = hnsw_filter_bitmap(h, filters[q0 + i], &bms[(size_t) i]))) return rc;
-                any_filter = true;
-            }
-        }
-        HIPCHK(hipMemcpyAsync(h->d_q.p, qpad.data(), (size_t) n * qfloats * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(h->d_bm.p, bms.data(), (size_t) n * sizeof(uint64_t*), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemsetAsync(h->d_vis.p, 0, (size_t) n * vwords * 4, ctx->stream));
-        char* d = h->d_out.as<char>();
-        HnswParams p{};
-        p.rows = c->d_rows;
-        p.stride4 = c->stride4;
-        p.metric = metric;
-        p.queries = h->d_q.as<float>();
-        p.n_elem = (uint32_t) h->n_elem;
-        p.entry = h->entry;
-        p.entry_level = h->entry_level;
-        p.m = (uint32_t) h->m;
-        p.max_level = (uint32_t) h->max_level;
-        p.elem_row = h->d_elem_row;
-        p.nbr0 = h->d_nbr0;
-        p.up_slot = h->d_up_slot;
-        p.up_nbr = h->d_up_nbr;
-        p.level = h->d_level;
-        p.tid_count = h->d_tid_count;
-        p.tids = h->d_tids;
-        p.bitmaps = any_filter ? h->d_bm.as<const uint64_t*>() : nullptr;
-        p.ef = (uint32_t) ef;
-        p.k = (uint32_t) k;
-        p.caps = (uint32_t) (2 * ef + 2 * h->m + 64);
-        p.visited = h->d_vis.as<uint32_t>();
-        p.visited_words = vwords;
-        p.block_ids = c->d_block;
-        p.doc_ids = c->d_doc;
-        p.orig_rows = c->d_orig;
-        p.out_block = reinterpret_cast<int64_t*>(d + o_blk);
-        p.out_doc = reinterpret_cast<int32_t*>(d + o_doc);
-        p.out_row = reinterpret_cast<int64_t*>(d + o_row);
-        p.out_dist = reinterpret_cast<float*>(d + o_dist);
-        p.out_count = reinterpret_cast<int32_t*>(d + o_cnt);
-        p.out_visited = reinterpret_cast<int64_t*>(d + o_vis);
-        p.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;
-        HIPCHK(launch_hnsw_search(p, (uint32_t) n, ctx->stream));
-        HIPCHK(hipMemcpyAsync(h->h_out.p, d, total, hipMemcpyDeviceToHost, ctx->stream));
+        int r;
+        HIPCHK(hipMemcpyAsync(h->d_q.p, qs, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        if ((r = hnsw_bitmaps(h, ctx, fs, 0, n, any_filter))) return r;
+        if ((r = hnsw_launch(h, ctx, h->d_q.as<float>(), (uint32_t) dim, n, k, ef, metric,
+                             any_filter ? h->d_bm.as<const uint64_t*>() : nullptr, force_global, reinterpret_cast<int64_t*>(d + o_blk),
+                             reinterpret_cast<int32_t*>(d + o_doc), reinterpret_cast<int64_t*>(d + o_row),
+                             reinterpret_cast<float*>(d + o_dist), reinterpret_cast<int32_t*>(d + o_cnt),
+                             reinterpret_cast<int64_t*>(d + o_vis), reinterpret_cast<int32_t*>(d + o_st))))
+            return r;
+        HIPCHK(hipMemcpyAsync(hh, d, total, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        const char* hh = h->h_out.as<char>();
-        const size_t off = (size_t) q0 * k, cnt = (size_t) n * k;
-        memcpy(out_blk + off, hh + o_blk, cnt * 8);
-        if (out_row) memcpy(out_row + off, hh + o_row, cnt * 8);
-        if (out_doc) memcpy(out_doc + off, hh + o_doc, cnt * 4);
-        memcpy(out_dist + off, hh + o_dist, cnt * 4);
-        memcpy(out_cnt + q0, hh + o_cnt, (size_t) n * 4);
-        if (out_visited) memcpy(out_visited + q0, hh + o_vis, (size_t) n * 8);
+        return VSR_OK;
+    };
+    if ((rc = run(queries, nq, filters, false))) return rc;
+    memcpy(out_blk, hh + o_blk, nk * 8);
+    if (out_row) memcpy(out_row, hh + o_row, nk * 8);
+    if (out_doc) memcpy(out_doc, hh + o_doc, nk * 4);
+    memcpy(out_dist, hh + o_dist, nk * 4);
+    memcpy(out_cnt, hh + o_cnt, (size_t) nq * 4);
+    if (out_visited) memcpy(out_visited, hh + o_vis, (size_t) nq * 8);
+    std::vector<int> redo;
+    for (int i = 0; i < nq; ++i)
+        if (reinterpret_cast<const int32_t*>(hh + o_st)[i]) redo.push_back(i);
+    if (!redo.empty()) {
+        std::vector<float> q2(redo.size() * (size_t) dim);
+        std::vector<const vsr_filter*> f2(redo.size(), nullptr);
+        for (size_t j = 0; j < redo.size(); ++j) {
+            memcpy(&q2[j * (size_t) dim], queries + (size_t) redo[j] * dim, (size_t) dim * sizeof(float));
+            if (filters) f2[j] = filters[redo[j]];
+        }
+        if ((rc = run(q2.data(), (int) redo.size(), f2.data(), true))) return rc;
+        for (size_t j = 0; j < redo.size(); ++j) {
+            const size_t src = j * (size_t) k, dst = (size_t) redo[j] * k;
+            memcpy(out_blk + dst, reinterpret_cast<int64_t*>(hh + o_blk) + src, (size_t) k * 8);
+            if (out_row) memcpy(out_row + dst, reinterpret_cast<int64_t*>(hh + o_row) + src, (size_t) k * 8);
+            if (out_doc) memcpy(out_doc + dst, reinterpret_cast<int32_t*>(hh + o_doc) + src, (size_t) k * 4);
+            memcpy(out_dist + dst, reinterpret_cast<float*>(hh + o_dist) + src, (size_t) k * 4);
+            out_cnt[redo[j]] = reinterpret_cast<int32_t*>(hh + o_cnt)[j];
+            if (out_visited) out_visited[redo[j]] = reinterpret_cast<int64_t*>(hh + o_vis)[j];
+        }
     }
     return VSR_OK;
 }

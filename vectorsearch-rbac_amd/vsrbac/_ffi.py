@@ -65,6 +65,7 @@ SYMBOLS = {
     "vsr_hnsw_load": (_i, [_vp, _i, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "vsr_hnsw_free": (_i, [_vp]),
     "vsr_hnsw_search": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vsr_hnsw_search_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_vector_norms": (_i, [_vp, _vp, _i64, _i, _vp]),
     "vsr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _vp]),
     "vsr_spherical_distances": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),

@@ -412,6 +412,14 @@ class HnswIndex:
         except Exception:
             pass
 
+    def search_device(self, d_queries, nq, k, ef_search, metric, filters, d_block, d_doc, d_rows, d_dist, d_counts,
+                      d_visited=None):
+        """Device pointers (ints); ONE launch on the corpus context's stream, no synchronisation (vsr_hnsw_search_device)."""
+        farr, keep = self.corpus._filter_array(filters, nq)
+        check(self._lib.vsr_hnsw_search_device(self._h, d_queries, nq, self.corpus.dim, int(k), int(ef_search), _metric(metric),
+                                               farr, d_block, d_doc, d_rows, d_dist, d_counts, d_visited))
+        return keep
+
     def search(self, queries, k, ef_search=40, metric="l2", filters=None):
         """SearchResult plus, as a second value, the number of elements each query visited on layer 0."""
         q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries, dtype=np.float32)))
