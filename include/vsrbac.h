@@ -204,8 +204,15 @@ int vsr_pair_distances(vsr_ctx* ctx, int metric, const float* a, const float* b,
 typedef struct vsr_ivf vsr_ivf;
 int vsr_ivf_load(vsr_corpus* corpus, const float* centers, int lists, const int32_t* row_list, vsr_ivf** out);
 int vsr_ivf_free(vsr_ivf* ivf);       /* before vsr_corpus_free of its corpus */
-/* index build, the pass over every row (ivfbuild.c:404-445): out_row_list[i] = nearest of `lists` centres for caller row
- * i under the opclass distance, ties to the lower list id -- what vsr_ivf_load takes.  Host pointers; synchronises. */
+/* index build, step 1 (ivfbuild.c:404-445 ComputeCenters -> ivfkmeans.c:21-93,259-498): k-means++ seeding and Elkan's
+ * k-means over the sampled rows (samples[n_samples][dim], the caller samples max(lists * 50, 10000) rows like
+ * ivfbuild.c:421-445); L2 for vector_l2_ops, the spherical variant for the inner-product and cosine opclasses.  The
+ * random draws come from a seeded xorshift64* stream (PostgreSQL's RandomDouble is not reproducible outside a backend).
+ * out_centers[lists][dim]; out_iterations (may be NULL) = Elkan iterations run.  Host pointers; synchronises. */
+int vsr_ivf_kmeans(vsr_ctx* ctx, int metric, int dim, const float* samples, int64_t n_samples, int lists, uint64_t seed,
+                   float* out_centers, int* out_iterations);
+/* index build, step 2, the pass over every row (ivfbuild.c:141-227): out_row_list[i] = nearest of `lists` centres for caller
+ * row i under the opclass distance, ties to the lower list id -- what vsr_ivf_load takes.  Host pointers; synchronises. */
 int vsr_ivf_assign(vsr_corpus* corpus, const float* centers, int lists, int metric, int32_t* out_row_list);
 int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim, int probes, int metric, int32_t* out_lists /* nq*probes */);
 int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, int probes, int metric,

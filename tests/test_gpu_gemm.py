@@ -57,7 +57,7 @@ def _search_async(ctx, corpus, q, k, metric, filters=None):
     return SearchResult(o_blk.cpu().numpy(), o_doc.cpu().numpy(), o_row.cpu().numpy(), o_dist.cpu().numpy(), o_cnt.cpu().numpy())
 
 
-@pytest.mark.parametrize("dim,nq,n", [(320, 129, 50_001), (768, 300, 40_000), (512, 700, 30_123), (1000, 257, 25_000)])
+@pytest.mark.parametrize("dim,nq,n", [(320, 129, 50_001), (768, 300, 60_000), (512, 700, 50_123), (1000, 257, 50_000)])
 def test_gemm_path_is_exact_on_integer_rows(ctx, oracle, dim, nq, n):
     """Unfiltered batches and big shared filters (one part seen by every query) of more than 128 queries take K2g: ragged
     row counts, 1..3 passes per part (129 -> 1 pass of 144 slots, 300 -> 2 x 160, 700 -> 3 x 240), 5..16 K-steps, ranges

@@ -304,3 +304,57 @@ def test_hnsw_limits_device_api_and_visited_forms(ctx, oracle, monkeypatch):
     monkeypatch.delenv("VSR_HNSW_VISITED")
     gpu.free()
     corpus.free()
+
+
+@pytest.mark.parametrize("lists,n", [(50, 60_000), (7, 3_000)])
+def test_ivf_kmeans_on_the_gpu_equals_the_oracle(ctx, oracle, sift60k, lists, n):
+    """vsr_ivf_kmeans (k-means++ + Elkan, ivfkmeans.c) against orc_ivf_kmeans: the same seed and samples give the same
+    centres BIT FOR BIT (L2 opclass, integer-valued rows: every float sum is exact and the random stream, the bound tests
+    and the centre order are the reference's); the whole build (kmeans -> assign -> load) then answers like an index
+    loaded from the oracle's arrays."""
+    x, blk, doc, oivf50 = sift60k
+    x = x[:n]
+    want = max(lists * 50, 10000)
+    rng = np.random.default_rng(9)
+    pick = np.sort(rng.choice(n, size=min(n, want), replace=False))
+    samples = np.ascontiguousarray(x[pick])
+    ref = np.zeros((lists, x.shape[1]), dtype=np.float32)
+    from oracle.oracle import METRICS
+    assert oracle.lib.orc_ivf_kmeans(METRICS["l2"], x.shape[1], samples, len(samples), lists, 9, ref) == 0
+    got, iters = ctx.ivf_kmeans(samples, lists, "l2", seed=9)
+    assert iters >= 2
+    np.testing.assert_array_equal(got, ref)
+    if lists == 50:
+        np.testing.assert_array_equal(got, oivf50.centers)             # (the fixture's index: same seed, same sampling rule)
+        corpus = ctx.load_corpus(x, blk[:n], doc[:n])
+        gpu, centers, row_list = corpus.build_ivf(x, lists, "l2", seed=9)
+        np.testing.assert_array_equal(centers, oivf50.centers)
+        np.testing.assert_array_equal(row_list, oivf50.assign)
+        q = x[rng.integers(0, n, 6)]
+        res = gpu.search(q, 20, 3, "l2")
+        for i in range(6):
+            idx, dist = oivf50.search(q[i], 20, 3)
+            np.testing.assert_array_equal(res.rows[i], idx)
+        gpu.free()
+        corpus.free()
+    # no samples at all: RandomCenters (ivfkmeans.c:124-147)
+    ref0 = np.zeros((lists, 8), dtype=np.float32)
+    assert oracle.lib.orc_ivf_kmeans(METRICS["l2"], 8, np.zeros((0, 8), dtype=np.float32), 0, lists, 5, ref0) == 0
+    got0, _ = ctx.ivf_kmeans(np.zeros((0, 8), dtype=np.float32), lists, "l2", seed=5)
+    np.testing.assert_array_equal(got0, ref0)
+
+
+def test_ivf_kmeans_spherical_variant(ctx, oracle):
+    """Inner-product / cosine opclasses: spherical k-means (unit centres, angular distance through acos): centres within
+    1e-6 of the oracle's and the same assignment of every row."""
+    from oracle.oracle import METRICS
+    rng = np.random.default_rng(17)
+    n, dim, lists = 20_000, 48, 20
+    x = rng.normal(size=(n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    samples = np.ascontiguousarray(x[:10_000])
+    ref = np.zeros((lists, dim), dtype=np.float32)
+    assert oracle.lib.orc_ivf_kmeans(METRICS["cosine"], dim, samples, len(samples), lists, 3, ref) == 0
+    got, _ = ctx.ivf_kmeans(samples, lists, "cosine", seed=3)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-6)

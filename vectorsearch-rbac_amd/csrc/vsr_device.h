@@ -261,6 +261,14 @@ hipError_t launch_mfmaw(const ScanParams& p, int metric, uint32_t n_blocks, hipS
 // per element on the coarse planes (hi = bf16(x) only; rows padded to whole 64-element K-steps)
 constexpr uint32_t GM_QMAX = 256;
 inline uint32_t coarse_stride4(int dim) { return 8u * (uint32_t) ((dim + 63) / 64); }
+// Coarse planes are stored K-step-major in blocks of 256 rows: block b = rows 256 b .. 256 b + 255, inside it one 16 KB slab
+// per K-step (32 elements = 4 chunks of 16 bytes per row), rows in order inside a slab.  Offsets in 16-byte units:
+constexpr uint32_t COARSE_SLAB_U4 = 256 * 4;
+__host__ __device__ inline size_t coarse_row_offset(uint32_t row, uint32_t nks)     // of the row's K-step 0 chunk 0; + ks * COARSE_SLAB_U4 + chunk
+{
+    return ((size_t) (row >> 8) * nks) * COARSE_SLAB_U4 + (size_t) (row & 255u) * 4u;
+}
+inline size_t coarse_plane_u4(uint64_t n_rows, uint32_t cstride4) { return ((n_rows + 255) / 256) * 256 * (size_t) cstride4; }
 // relative error bound of the coarse product xh * qh accumulated in fp32: |dot_s - dot| <= g |x| |q|
 inline float coarse_err_g(int dim) { return 3.9138794e-3f + (float) (dim + 64) * 5.9604645e-8f; }     // 2^-8 (1 + 2^-9) + ...
 hipError_t launch_gemm(const ScanParams& p, int metric, uint32_t n_blocks, hipStream_t s);

@@ -12,6 +12,9 @@
 //   * operands are written into LDS by the load itself (global_load_lds_dwordx4: no staging registers, no ds_write), the
 //     XOR swizzle of the 128-byte LDS rows is applied on the SOURCE address (cdna_hip_programming.md, rule 21);
 //   * two stage buffers; the loads of K-step s + 1 are in flight under the MFMAs of step s, one barrier per K-step;
+//   * the coarse planes are stored K-STEP-MAJOR in blocks of 256 rows (coarse_row_offset, vsr_device.h): the 64 bytes that
+//     256 consecutive rows contribute to one K-step are one contiguous 16 KB slab, so an unfiltered tile streams whole
+//     slabs (row-major planes made every K-step a 64-byte-per-1536-byte column walk over HBM: measured 2.5 TB/s);
 //   * ONE product per element: the COARSE screening planes hold only hi = bf16(x) (vsr_corpus::d_scr_c), so a dot
 //     product is x.q ~ xh.qh with |error| <= g |x||q|, g = 2^-8 (1 + 2^-9) + (d + 64) 2^-24 (bf16 rounds to nearest:
 //     2^-9 relative per operand; fp32 accumulation).  That is 1/3 of K2w's products and 1/2 of its bytes.  The
@@ -192,22 +195,22 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
     for (int pc = 0; pc < 2; ++pc) {
         const uint32_t qs = (uint32_t) (wave * 2 + pc) * 16u + l_slot;
         const uint32_t slot = p.q_slots[grp.q_begin + (qs < q_count ? qs : 0u)];
-        b_src[pc] = p.q_scr_c + (size_t) slot * cstride4 + l_src;
+        b_src[pc] = p.q_scr_c + coarse_row_offset(slot, nks) + l_src;
     }
     auto rows_of = [&](uint32_t it_, const uint4* (&dst)[2]) {
         const int32_t* ridx = rowidx + (it_ & 1u) * GM_BM;
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
             const int32_t r = ridx[(wave * 2 + pc) * 16 + (int) l_slot];
-            dst[pc] = p.scr_c + (size_t) (uint32_t) (r < 0 ? 0 : r) * cstride4 + l_src;
+            dst[pc] = p.scr_c + coarse_row_offset((uint32_t) (r < 0 ? 0 : r), nks) + l_src;
         }
     };
     auto issue = [&](const uint4* (&a)[2], uint32_t ks, uint32_t slot_) {
         lds_u4* dst = (lds_u4*) (stage + (size_t) slot_ * GM_STAGE_U4);
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
-            __builtin_amdgcn_global_load_lds(as_global(a[pc] + ks * GM_KC), dst + (wave * 2 + pc) * 64, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(as_global(b_src[pc] + ks * GM_KC), dst + GM_BM * GM_KC + (wave * 2 + pc) * 64, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(as_global(a[pc] + (size_t) ks * COARSE_SLAB_U4), dst + (wave * 2 + pc) * 64, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(as_global(b_src[pc] + (size_t) ks * COARSE_SLAB_U4), dst + GM_BM * GM_KC + (wave * 2 + pc) * 64, 16, 0, 0);
         }
     };
 

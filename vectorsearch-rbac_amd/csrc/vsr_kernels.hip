@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void split_coarse_kernel(const float4* rows, u
     const uint64_t total = (uint64_t) n_rows * cstride4;
     for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t) gridDim.x * 256) {
         const uint32_t r = (uint32_t) (i / cstride4), c = (uint32_t) (i % cstride4);
-        scr_c[i] = coarse8(rows + (size_t) r * stride4, stride4, c);
+        scr_c[coarse_row_offset(r, cstride4 / 4) + (size_t) (c >> 2) * COARSE_SLAB_U4 + (c & 3u)] = coarse8(rows + (size_t) r * stride4, stride4, c);
     }
 }
 
@@ -703,7 +703,8 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageParams p)
     }
     if (p.q_scr_c)                                           // K2g: the query's coarse plane
         for (uint32_t c = (uint32_t) tid; c < p.cstride4; c += 256)
-            p.q_scr_c[(size_t) s * p.cstride4 + c] = coarse8(reinterpret_cast<const float4*>(dst), p.qfloats / 4, c);
+            p.q_scr_c[coarse_row_offset(s, p.cstride4 / 4) + (size_t) (c >> 2) * COARSE_SLAB_U4 + (c & 3u)] =
+                coarse8(reinterpret_cast<const float4*>(dst), p.qfloats / 4, c);
     if (p.q_scr8 && tid >= 64 && tid < 72) {                 // int8 path: the query as q - 128, validated
         const uint32_t c = (uint32_t) tid - 64;
         uint4 out;

@@ -1,0 +1,360 @@
+// vsr_kmeans.hip — IVFFlat index build on the GPU: k-means++ seeding and Elkan's k-means over the sampled rows
+// (pgvector/src/ivfkmeans.c:21-93 InitCenters, :192-246 ComputeNewCenters, :259-498 ElkanKmeans; ivfbuild.c:404-445
+// ComputeCenters calls it on max(lists * 50, 10000) sampled rows).  The pass over every row that follows (row -> nearest
+// centre, ivfbuild.c:141-227) is vsr_ivf_assign (vsr_runtime.hip).
+//
+// Parity definition.  The reference's result depends on (a) its random stream (RandomDouble / RandomInt of a PostgreSQL
+// backend: not reproducible outside one; a seeded xorshift64* stands in here, the same one the CPU checker uses), (b) the
+// order of its floating-point operations.  This file keeps BOTH: every sample runs the reference's bound tests in the
+// reference's centre order with the reference's float / double types, distances are summed left to right without
+// contraction, new centres are summed in sample order.  What runs in parallel is what is independent in the reference too:
+// samples within an assignment step, (centre, dimension) pairs of the mean, (centre, centre) pairs of the half-distance
+// matrix.  The one serial piece -- the weighted draw of k-means++ walks the samples subtracting weights -- is a one-thread
+// kernel (the distance sweep before it is parallel).  Same seed and samples => the same centres as the checker bit for bit
+// for L2; the spherical variant (inner product / cosine opclasses) goes through acos(), whose last bit may differ between
+// the device's and the host's libm: there the centres agree within 1e-6 and the assignments are checked instead.
+#include "../../include/vsrbac.h"
+#include "vsr_device.h"
+
+#include <cfloat>
+#include <cstdio>
+
+namespace vsr {
+
+struct KmRng { uint64_t s; };
+__host__ __device__ inline uint64_t km_next(KmRng* r)
+{
+    uint64_t x = r->s;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    r->s = x;
+    return x * 0x2545F4914F6CDD1DULL;
+}
+__host__ __device__ inline double km_double(KmRng* r) { return (double) (km_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+__host__ __device__ inline void km_seed(KmRng* r, uint64_t seed)
+{
+    r->s = seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
+    if (!r->s) r->s = 1;
+    (void) km_next(r);
+}
+
+// IVFFLAT_KMEANS_DISTANCE_PROC: l2_distance for vector_l2_ops, vector_spherical_distance for ip / cosine (vector.sql:292-333)
+__device__ __forceinline__ double km_distance(int metric, int dim, const float* a, const float* b)
+{
+    float sum = 0.0f;
+    if (metric == M_L2) {
+        for (int i = 0; i < dim; ++i) {
+            const float d = __fsub_rn(a[i], b[i]);
+            sum = __fadd_rn(sum, __fmul_rn(d, d));
+        }
+        return sqrt((double) sum);                                            // vector.c:568-578
+    }
+    for (int i = 0; i < dim; ++i) sum = __fadd_rn(sum, __fmul_rn(a[i], b[i]));
+    double d = (double) sum;                                                  // vector.c:692-711
+    if (d > 1) d = 1; else if (d < -1) d = -1;
+    return acos(d) / 3.14159265358979323846;
+}
+
+// l2_normalize of one centre in place (vector.c:774-808; a centre that overflows stays as it is, like NormCenters)
+__device__ inline void km_norm_center(int dim, float* c)
+{
+    double norm = 0;
+    for (int i = 0; i < dim; ++i) norm += (double) c[i] * (double) c[i];
+    norm = sqrt(norm);
+    if (!(norm > 0)) { for (int i = 0; i < dim; ++i) c[i] = 0.0f; return; }
+    bool inf = false;
+    for (int i = 0; i < dim; ++i) inf |= isinf((float) (c[i] / norm));
+    if (inf) return;
+    for (int i = 0; i < dim; ++i) c[i] = (float) (c[i] / norm);
+}
+
+struct KmState {
+    int metric, dim, nc;
+    int64_t ns;
+    const float* samples;      // [ns][dim]
+    float* centers;            // [nc][dim]
+    float* newc;               // [nc][dim]
+    float* lower;              // [ns][nc]
+    float* upper;              // [ns]
+    float* weight;             // [ns]
+    float* s;                  // [nc]
+    float* half;               // [nc][nc]
+    float* newcdist;           // [nc]
+    int* counts;               // [nc]
+    int* closest;              // [ns]
+    int* changes;              // [1]
+    KmRng* rng;                // [1]
+};
+
+__global__ __launch_bounds__(1) void km_first_center_kernel(KmState k)
+{
+    const int64_t j = (int64_t) (km_next(k.rng) % (uint64_t) k.ns);
+    for (int t = 0; t < k.dim; ++t) k.centers[t] = k.samples[(size_t) j * k.dim + t];
+}
+
+// k-means++: distances of every sample to centre i, running minimum of their squares (ivfkmeans.c:45-63)
+__global__ __launch_bounds__(256) void km_seed_sweep_kernel(KmState k, int i)
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= k.ns) return;
+    double d = km_distance(k.metric, k.dim, k.samples + (size_t) j * k.dim, k.centers + (size_t) i * k.dim);
+    k.lower[(size_t) j * k.nc + i] = (float) d;
+    d *= d;
+    if (i == 0) k.weight[j] = FLT_MAX;
+    if (d < k.weight[j]) k.weight[j] = (float) d;
+}
+
+// ... and the weighted draw of the next centre (ivfkmeans.c:65-90): serial by definition (one thread)
+__global__ __launch_bounds__(1) void km_seed_pick_kernel(KmState k, int i)
+{
+    double sum = 0.0;
+    for (int64_t j = 0; j < k.ns; ++j) sum += k.weight[j];
+    double choice = sum * km_double(k.rng);
+    int64_t j;
+    for (j = 0; j < k.ns - 1; ++j) {
+        choice -= k.weight[j];
+        if (choice <= 0) break;
+    }
+    for (int t = 0; t < k.dim; ++t) k.centers[(size_t) (i + 1) * k.dim + t] = k.samples[(size_t) j * k.dim + t];
+}
+
+__global__ __launch_bounds__(256) void km_init_assign_kernel(KmState k)      // ivfkmeans.c:325-345
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= k.ns) return;
+    float mind = FLT_MAX;
+    int cc = 0;
+    for (int c = 0; c < k.nc; ++c)
+        if (k.lower[(size_t) j * k.nc + c] < mind) { mind = k.lower[(size_t) j * k.nc + c]; cc = c; }
+    k.upper[j] = mind;
+    k.closest[j] = cc;
+}
+
+__global__ __launch_bounds__(256) void km_half_kernel(KmState k)             // ivfkmeans.c:361-372
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t) k.nc * k.nc) return;
+    const int a = (int) (i / k.nc), b = (int) (i % k.nc);
+    if (a >= b) return;
+    const float d = (float) (0.5 * km_distance(k.metric, k.dim, k.centers + (size_t) a * k.dim, k.centers + (size_t) b * k.dim));
+    k.half[(size_t) a * k.nc + b] = d;
+    k.half[(size_t) b * k.nc + a] = d;
+}
+
+__global__ __launch_bounds__(256) void km_s_kernel(KmState k)                // ivfkmeans.c:375-388
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= k.nc) return;
+    float mind = FLT_MAX;
+    for (int c = 0; c < k.nc; ++c)
+        if (j != c && k.half[(size_t) j * k.nc + c] < mind) mind = k.half[(size_t) j * k.nc + c];
+    k.s[j] = mind;
+    if (j == 0) *k.changes = 0;
+}
+
+// the assignment step of Elkan's algorithm for one sample, bound tests in the reference's order (ivfkmeans.c:392-451)
+__global__ __launch_bounds__(256) void km_assign_kernel(KmState k, int rjreset)
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= k.ns) return;
+    const float* x = k.samples + (size_t) j * k.dim;
+    float* lo = k.lower + (size_t) j * k.nc;
+    float up = k.upper[j];
+    int cl = k.closest[j];
+    int changed = 0;
+    if (!(up <= k.s[cl])) {
+        int rj = rjreset;
+        for (int c = 0; c < k.nc; ++c) {
+            float dxcx;
+            if (c == cl) continue;
+            if (up <= lo[c]) continue;
+            if (up <= k.half[(size_t) cl * k.nc + c]) continue;
+            if (rj) {
+                dxcx = (float) km_distance(k.metric, k.dim, x, k.centers + (size_t) cl * k.dim);
+                lo[cl] = dxcx;
+                up = dxcx;
+                rj = 0;
+            } else
+                dxcx = up;
+            if (dxcx > lo[c] || dxcx > k.half[(size_t) cl * k.nc + c]) {
+                const float dxc = (float) km_distance(k.metric, k.dim, x, k.centers + (size_t) c * k.dim);
+                lo[c] = dxc;
+                if (dxc < dxcx) {
+                    cl = c;
+                    up = dxc;
+                    ++changed;
+                }
+            }
+        }
+    }
+    k.upper[j] = up;
+    k.closest[j] = cl;
+    if (changed) atomicAdd(k.changes, changed);
+}
+
+// ComputeNewCenters (ivfkmeans.c:192-246): float sums in sample order -- one thread per (centre, dimension) walks the
+// samples in order, so the additions happen in the reference's order
+__global__ __launch_bounds__(256) void km_count_kernel(KmState k)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= k.nc) return;
+    int n = 0;
+    for (int64_t j = 0; j < k.ns; ++j) n += k.closest[j] == c;
+    k.counts[c] = n;
+}
+
+__global__ __launch_bounds__(256) void km_sum_kernel(KmState k)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t) k.nc * k.dim) return;
+    const int c = (int) (i / k.dim), t = (int) (i % k.dim);
+    float sum = 0.0f;
+    for (int64_t j = 0; j < k.ns; ++j)
+        if (k.closest[j] == c) sum = __fadd_rn(sum, k.samples[(size_t) j * k.dim + t]);
+    const int n = k.counts[c];
+    if (n > 0) {
+        if (isinf(sum)) sum = sum > 0 ? FLT_MAX : -FLT_MAX;
+        sum = __fdiv_rn(sum, (float) n);
+    }
+    k.newc[i] = sum;
+}
+
+// empty centres get random values, in centre order (the stream is serial); spherical variant: centres normalised
+__global__ __launch_bounds__(1) void km_fix_centers_kernel(KmState k)
+{
+    for (int c = 0; c < k.nc; ++c) {
+        float* x = k.newc + (size_t) c * k.dim;
+        if (k.counts[c] == 0)
+            for (int t = 0; t < k.dim; ++t) x[t] = (float) km_double(k.rng);
+        if (k.metric != M_L2) km_norm_center(k.dim, x);
+    }
+}
+
+__global__ __launch_bounds__(256) void km_newcdist_kernel(KmState k)         // ivfkmeans.c:459-462
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= k.nc) return;
+    k.newcdist[c] = (float) km_distance(k.metric, k.dim, k.centers + (size_t) c * k.dim, k.newc + (size_t) c * k.dim);
+}
+
+__global__ __launch_bounds__(256) void km_bounds_kernel(KmState k)           // ivfkmeans.c:464-487
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= k.ns) return;
+    for (int c = 0; c < k.nc; ++c) {
+        const float d = __fsub_rn(k.lower[(size_t) j * k.nc + c], k.newcdist[c]);
+        k.lower[(size_t) j * k.nc + c] = d < 0 ? 0 : d;
+    }
+    k.upper[j] = __fadd_rn(k.upper[j], k.newcdist[k.closest[j]]);
+}
+
+__global__ __launch_bounds__(256) void km_random_centers_kernel(KmState k)   // RandomCenters, ivfkmeans.c:124-147 (no samples)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    for (int64_t i = 0; i < (int64_t) k.nc * k.dim; ++i) k.centers[i] = (float) km_double(k.rng);
+    if (k.metric != M_L2)
+        for (int c = 0; c < k.nc; ++c) km_norm_center(k.dim, k.centers + (size_t) c * k.dim);
+}
+
+}  // namespace vsr
+
+using namespace vsr;
+
+#define KM_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) { rc = vsr_kmeans_fail(#expr, hipGetErrorString(e_), e_ == hipErrorOutOfMemory); goto done; } \
+    } while (0)
+
+int vsr_kmeans_fail(const char* what, const char* why, bool oom);     // vsr_runtime.hip: sets vsr_last_error
+int vsr_ctx_device(const vsr_ctx* ctx, hipStream_t* stream);          // vsr_runtime.hip
+
+extern "C" int vsr_ivf_kmeans(vsr_ctx* ctx, int metric, int dim, const float* samples, int64_t n_samples, int lists, uint64_t seed,
+                              float* out_centers, int* out_iterations)
+{
+    int rc = VSR_OK;
+    hipStream_t st = nullptr;
+    if (!ctx || !out_centers || n_samples < 0 || (n_samples > 0 && !samples))
+        return vsr_kmeans_fail("vsr_ivf_kmeans", "NULL argument", false), VSR_ERR_INVALID;
+    if (dim < 1 || dim > 16000 || lists < 1 || lists > 32768)      /* IVFFLAT_MAX_LISTS, ivfflat.h:44 */
+        return vsr_kmeans_fail("vsr_ivf_kmeans", "dim must be 1..16000 and lists 1..32768", false), VSR_ERR_INVALID;
+    if (metric != VSR_METRIC_L2 && metric != VSR_METRIC_IP && metric != VSR_METRIC_COSINE)
+        return vsr_kmeans_fail("vsr_ivf_kmeans", "metric has no ivfflat operator class", false), VSR_ERR_UNSUPPORTED;
+    if (out_iterations) *out_iterations = 0;
+    const int dev = vsr_ctx_device(ctx, &st);
+    if (hipSetDevice(dev) != hipSuccess) return vsr_kmeans_fail("hipSetDevice", "failed", false), VSR_ERR_HIP;
+    const int nc = lists;
+    const int64_t ns = n_samples;
+    KmState k{};
+    k.metric = metric == VSR_METRIC_L2 ? M_L2 : M_IP;
+    k.dim = dim;
+    k.nc = nc;
+    k.ns = ns;
+    void* bufs[16] = {nullptr};
+    int nb = 0;
+    auto alloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        bufs[nb++] = p;
+        return p;
+    };
+    KmRng h_rng;
+    km_seed(&h_rng, seed);
+    int iterations = 0;
+    {
+        float* d_samples = (float*) alloc((size_t) ns * dim * 4);
+        k.centers = (float*) alloc((size_t) nc * dim * 4);
+        k.newc = (float*) alloc((size_t) nc * dim * 4);
+        k.lower = (float*) alloc((size_t) ns * nc * 4);
+        k.upper = (float*) alloc((size_t) ns * 4);
+        k.weight = (float*) alloc((size_t) ns * 4);
+        k.s = (float*) alloc((size_t) nc * 4);
+        k.half = (float*) alloc((size_t) nc * nc * 4);
+        k.newcdist = (float*) alloc((size_t) nc * 4);
+        k.counts = (int*) alloc((size_t) nc * 4);
+        k.closest = (int*) alloc((size_t) ns * 4);
+        k.changes = (int*) alloc(16);
+        k.rng = (KmRng*) alloc(16);
+        k.samples = d_samples;
+        if (!d_samples || !k.centers || !k.newc || !k.lower || !k.upper || !k.weight || !k.s || !k.half || !k.newcdist || !k.counts ||
+            !k.closest || !k.changes || !k.rng) {
+            rc = vsr_kmeans_fail("vsr_ivf_kmeans", "out of device memory", true);
+            goto done;
+        }
+        KM_HIP(hipMemcpyAsync(k.rng, &h_rng, sizeof h_rng, hipMemcpyHostToDevice, st));
+        if (ns == 0) {
+            hipLaunchKernelGGL(km_random_centers_kernel, dim3(1), dim3(64), 0, st, k);
+        } else {
+            KM_HIP(hipMemcpyAsync(d_samples, samples, (size_t) ns * dim * 4, hipMemcpyHostToDevice, st));
+            const unsigned gs = (unsigned) ((ns + 255) / 256), gc = (unsigned) ((nc + 255) / 256);
+            hipLaunchKernelGGL(km_first_center_kernel, dim3(1), dim3(1), 0, st, k);
+            for (int i = 0; i < nc; ++i) {
+                hipLaunchKernelGGL(km_seed_sweep_kernel, dim3(gs), dim3(256), 0, st, k, i);
+                if (i + 1 < nc) hipLaunchKernelGGL(km_seed_pick_kernel, dim3(1), dim3(1), 0, st, k, i);
+            }
+            hipLaunchKernelGGL(km_init_assign_kernel, dim3(gs), dim3(256), 0, st, k);
+            for (int iteration = 0; iteration < 500; ++iteration) {
+                hipLaunchKernelGGL(km_half_kernel, dim3((unsigned) (((int64_t) nc * nc + 255) / 256)), dim3(256), 0, st, k);
+                hipLaunchKernelGGL(km_s_kernel, dim3(gc), dim3(256), 0, st, k);
+                hipLaunchKernelGGL(km_assign_kernel, dim3(gs), dim3(256), 0, st, k, iteration != 0 ? 1 : 0);
+                hipLaunchKernelGGL(km_count_kernel, dim3(gc), dim3(256), 0, st, k);
+                hipLaunchKernelGGL(km_sum_kernel, dim3((unsigned) (((int64_t) nc * dim + 255) / 256)), dim3(256), 0, st, k);
+                hipLaunchKernelGGL(km_fix_centers_kernel, dim3(1), dim3(1), 0, st, k);
+                hipLaunchKernelGGL(km_newcdist_kernel, dim3(gc), dim3(256), 0, st, k);
+                hipLaunchKernelGGL(km_bounds_kernel, dim3(gs), dim3(256), 0, st, k);
+                KM_HIP(hipMemcpyAsync(k.centers, k.newc, (size_t) nc * dim * 4, hipMemcpyDeviceToDevice, st));
+                int changes = 0;
+                KM_HIP(hipMemcpyAsync(&changes, k.changes, sizeof changes, hipMemcpyDeviceToHost, st));
+                KM_HIP(hipStreamSynchronize(st));
+                iterations = iteration + 1;
+                if (changes == 0 && iteration != 0) break;
+            }
+        }
+        KM_HIP(hipGetLastError());
+        KM_HIP(hipMemcpyAsync(out_centers, k.centers, (size_t) nc * dim * 4, hipMemcpyDeviceToHost, st));
+        KM_HIP(hipStreamSynchronize(st));
+        if (out_iterations) *out_iterations = iterations;
+    }
+done:
+    for (int i = 0; i < nb; ++i) (void) hipFree(bufs[i]);
+    return rc;
+}

@@ -50,6 +50,12 @@ static int fail(int status, const char* fmt, ...)
                         hipGetErrorString(e_));                                               \
     } while (0)
 
+// helpers of the other translation units of the library (vsr_kmeans.hip)
+int vsr_kmeans_fail(const char* what, const char* why, bool oom)
+{
+    return fail(oom ? VSR_ERR_OOM : VSR_ERR_HIP, "%s: %s", what, why);
+}
+
 // ---------------------------------------------------------------------------------------------
 // small RAII buffers (grow-only workspaces)
 // ---------------------------------------------------------------------------------------------
@@ -333,6 +339,12 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     return VSR_OK;
 }
 
+int vsr_ctx_device(const vsr_ctx* ctx, hipStream_t* stream)
+{
+    if (stream) *stream = ctx->stream;
+    return ctx->device;
+}
+
 extern "C" int vsr_close(vsr_ctx* ctx)
 {
     if (!ctx) return VSR_OK;
@@ -589,7 +601,7 @@ extern "C" int vsr_corpus_load(vsr_ctx* ctx, const float* rows, int64_t n, int d
             // the hi + mid planes and one product per element; wide passes (> 128 queries per filter part) screen on them
             if (mfmaw_qmax(c->pstride4, !c->scr_has_mid) > 64 && !getenv("VSR_NO_COARSE")) {
                 c->cstride4 = coarse_stride4(dim);
-                HIPCHK(hipMalloc(&c->d_scr_c, alloc_rows * (size_t) c->cstride4 * 16 + 1024));
+                HIPCHK(hipMalloc(&c->d_scr_c, coarse_plane_u4((uint64_t) alloc_rows, c->cstride4) * 16 + 1024));
                 HIPCHK(launch_split_coarse(c->d_rows, (uint32_t) n, c->stride4, c->d_scr_c, c->cstride4, ctx->stream));
                 HIPCHK(hipStreamSynchronize(ctx->stream));
             }
@@ -1588,7 +1600,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     const size_t off_qn = align_up(off_q + (size_t) nq * qfloats * sizeof(float), 256);
     const size_t off_qp = align_up(off_qn + (size_t) nq * sizeof(float), 256);
     const size_t off_qc = align_up(off_qp + (size_t) nq * q_pstride * 16, 256);            // K2g: coarse query planes
-    const size_t off_q8 = align_up(off_qc + (plan.k2g ? (size_t) nq * c->cstride4 * 16 : 0), 256);   // int8 query planes, |q-128|^2, validity
+    const size_t off_q8 = align_up(off_qc + (plan.k2g ? coarse_plane_u4((uint64_t) nq, c->cstride4) * 16 : 0), 256);   // int8 query planes, |q-128|^2, validity
     const size_t off_qn8 = align_up(off_q8 + (plan.int8 ? (size_t) nq * 128 : 0), 256);
     const size_t off_qb = align_up(off_qn8 + (plan.int8 ? (size_t) nq * sizeof(float) : 0), 256);
     const size_t off_g = align_up(off_qb + (plan.int8 ? (size_t) nq * sizeof(uint32_t) : 0), 256);    // copied from here on
@@ -2622,7 +2634,8 @@ extern "C" int vsr_ivf_load(vsr_corpus* c, const float* centers, int lists, cons
     if (!c || !out || !centers || (c->n > 0 && !row_list)) return fail(VSR_ERR_INVALID, "vsr_ivf_load: NULL argument");
     *out = nullptr;
     if (c->base) return fail(VSR_ERR_INVALID, "vsr_ivf_load: the corpus is itself a view");
-    if (lists < 1 || lists > 8192) return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_load: lists must be between 1 and 8192 (got %d)", lists);
+    if (lists < 1 || lists > 32768)      /* reloption lists: 1 .. IVFFLAT_MAX_LISTS (ivfflat.h:42-44) */
+        return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_load: lists must be between 1 and 32768 (got %d)", lists);
     vsr_ctx* ctx = c->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = c->n;
@@ -2801,14 +2814,14 @@ extern "C" int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim
     return VSR_OK;
 }
 
-// Index build, the part that touches every row (ivfbuild.c:404-445: InsertTuples finds the nearest list of each heap
+// Index build, the part that touches every row (ivfbuild.c:141-227: InsertTuple finds the nearest list of each heap
 // row): all corpus rows against the centres, in the index's arithmetic, on the GPU.  The k-means that produces the
-// centres from a small sample (ivfkmeans.c) is not on the GPU; see DESIGN.md section 7.
+// centres from the sampled rows (ivfbuild.c:404-445 ComputeCenters, ivfkmeans.c) is vsr_ivf_kmeans (vsr_kmeans.hip).
 extern "C" int vsr_ivf_assign(vsr_corpus* c, const float* centers, int lists, int metric, int32_t* out_row_list)
 {
     if (!c || !centers || (c->n > 0 && !out_row_list)) return fail(VSR_ERR_INVALID, "vsr_ivf_assign: NULL argument");
     if (c->base) return fail(VSR_ERR_INVALID, "vsr_ivf_assign: the corpus is a view");
-    if (lists < 1 || lists > 8192) return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_assign: lists must be between 1 and 8192 (got %d)", lists);
+    if (lists < 1 || lists > 32768) return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_assign: lists must be between 1 and 32768 (got %d)", lists);
     if (metric != VSR_METRIC_L2 && metric != VSR_METRIC_IP && metric != VSR_METRIC_COSINE)
         return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_assign: metric %d has no ivfflat opclass", metric);
     vsr_ctx* ctx = c->ctx;

@@ -143,6 +143,17 @@ class Context:
                                                 _ptr(out)))
         return out
 
+    def ivf_kmeans(self, samples, lists, metric="l2", seed=1):
+        """IVFFlat build, step 1 (ivfkmeans.c): k-means++ + Elkan's k-means over the sampled rows on the GPU.
+        Returns (centers[lists, dim], iterations)."""
+        s = np.ascontiguousarray(np.atleast_2d(np.asarray(samples, dtype=np.float32)))
+        ns, dim = (0, s.shape[1]) if s.size == 0 else s.shape
+        out = np.zeros((int(lists), dim), dtype=np.float32)
+        it = C.c_int(0)
+        check(self._lib.vsr_ivf_kmeans(self._h, _metric(metric), dim, _ptr(s), ns, int(lists), C.c_uint64(int(seed)), _ptr(out),
+                                       C.byref(it)))
+        return out, it.value
+
     def merge_topk_device(self, keys, block_ids, doc_ids, dist, n_parts, nq, k, out_block, out_doc, out_dist,
                           out_keys, out_counts):
         """Device pointers (ints).  Layout [n_parts][nq][k]."""
@@ -262,6 +273,19 @@ class Corpus:
     def load_ivf(self, centers, row_list):
         """IVFFlat index over this corpus: centres [lists, dim] and the list of every row (caller row order)."""
         return IvfIndex(self, centers, row_list)
+
+    def build_ivf(self, rows, lists=100, metric="l2", seed=1, sample=None):
+        """CREATE INDEX ... USING ivfflat on the GPU (ivfbuild.c:998-1019): sample max(lists * 50, 10000) of `rows` (this
+        corpus's rows in the caller's order, host array), k-means on the sample (vsr_ivf_kmeans), every row into its
+        nearest list (vsr_ivf_assign), list-ordered image (vsr_ivf_load).  Returns (IvfIndex, centers, row_list)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        n = rows.shape[0]
+        want = max(int(lists) * 50, 10000) if sample is None else int(sample)
+        rng = np.random.default_rng(seed)
+        pick = np.sort(rng.choice(n, size=min(n, want), replace=False)) if n else np.zeros(0, dtype=np.int64)
+        centers, _ = self.ctx.ivf_kmeans(rows[pick], lists, metric, seed)
+        row_list = self.ivf_assign(centers, metric)
+        return IvfIndex(self, centers, row_list), centers, row_list
 
     def load_hnsw(self, graph):
         """HNSW graph over this corpus; `graph`: dict with m, entry, level, nbr0, tid_count, tids, up_slot, up_nbr,
