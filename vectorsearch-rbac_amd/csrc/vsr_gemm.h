@@ -40,6 +40,15 @@
 
 namespace vsr {
 
+#ifndef GM_READS_UPFRONT
+#define GM_READS_UPFRONT 1
+#endif
+#ifndef GM_SETPRIO
+#define GM_SETPRIO 0
+#endif
+#ifndef GM_SCHED
+#define GM_SCHED 0
+#endif
 constexpr int GM_THREADS = 512;
 constexpr int GM_BM = 256;                 // rows per workgroup tile
 constexpr int GM_BN = 256;                 // query slots per pass
@@ -47,7 +56,8 @@ constexpr int GM_KC = 4;                   // 16-byte chunks (8 bf16) per row an
 constexpr int GM_SLOTS = 4;                // stage ring: one slot being multiplied, three in flight
 constexpr size_t GM_STAGE_U4 = (size_t) (GM_BM + GM_BN) * GM_KC;                  // uint4 per stage slot (32 KB)
 // [stage ring | row ring: index, value | column constants, thresholds | mapping scratch: descriptor, bitmap word, norm | flag]
-inline size_t gemm_lds_bytes() { return GM_SLOTS * GM_STAGE_U4 * 16 + 2 * GM_BM * 8 + GM_BN * 20 + GM_BM * 20 + 16; }
+constexpr int GM_PARK = 64;               // candidates a wave parks per tile before they go to their queries' buffers
+inline size_t gemm_lds_bytes() { return GM_SLOTS * GM_STAGE_U4 * 16 + 2 * GM_BM * 8 + GM_BN * 20 + GM_BM * 20 + 16 + 8 * (GM_PARK * 16 + 64 * 4); }
 
 using lds_u4 = __attribute__((address_space(3))) uint4;
 using lds_u32 = __attribute__((address_space(3))) uint32_t;
@@ -57,6 +67,12 @@ using lds_u32 = __attribute__((address_space(3))) uint32_t;
 // (cdna_hip_programming.md, "Pipelining across barriers").  Per K-step a wave issues its four operand pieces; the row
 // mapping of the next tile (descriptor -> row -> permission word, |row|^2) rides in the same queue as 4-byte LDS-DMA
 // loads into a scratch area and is read back two K-steps later, when the counted wait has covered it.
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void gm_wait_barrier()
 {
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -102,6 +118,12 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
     uint32_t* mapb = mapd + 2 * GM_BM;                                          // [2][256] permission word (lo | hi)
     float*    mapn = reinterpret_cast<float*>(mapb + 2 * GM_BM);                // [256] |row|^2
     uint32_t* s_open = reinterpret_cast<uint32_t*>(mapn + GM_BM);               // any query column without a threshold
+    // per wave: parked candidates {value bits, row, wave-local column, rank within the column} and the columns' counts
+    uint32_t* pk_v = s_open + 4 + (size_t) wave * (GM_PARK * 4 + 64);
+    uint32_t* pk_r = pk_v + GM_PARK;
+    uint32_t* pk_c = pk_r + GM_PARK;
+    uint32_t* pk_k = pk_c + GM_PARK;
+    uint32_t* pk_n = pk_k + GM_PARK;                                            // [64] candidates per column of this wave
     // (all LDS lives in the one dynamic array: a second __shared__ object beside LDS-DMA staging can cost a vmcnt(0) per
     // fragment read, cdna_hip_programming.md "Three .s-level traps")
 
@@ -220,6 +242,33 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
     const uint32_t frag_off = (uint32_t) li * GM_KC + ((uint32_t) kq ^ ((0u - ((uint32_t) li >> 2)) & 3u));   // + 64 per 16-slot block
     f32x4 acc[8][4];
 
+    // parked candidates of the previous tile -> their queries' buffers (see the epilogue)
+    uint32_t n_park = 0, n_flush = 0;                                           // wave-uniform
+    uint32_t fl_base = 0;                                                       // lane c: first position of column c's candidates
+    const uint32_t my_col_slot = __float_as_uint(colc[wn * 64 + lane].w);      // lane c: query slot of the wave's column c
+    auto flush_reserve = [&]() {
+        n_flush = n_park;
+        if (n_flush == 0) return;
+        pk_n[lane] = 0u;
+        wave_fence();
+        if ((uint32_t) lane < n_flush) pk_k[lane] = atomicAdd(&pk_n[pk_c[lane]], 1u);      // LDS: rank within its column
+        wave_fence();
+        const uint32_t mine = pk_n[lane];
+        if (mine) fl_base = atomicAdd(p.qcnt + my_col_slot, mine);             // one wave instruction; consumed a tile later
+    };
+    auto flush_store = [&]() {
+        if (n_flush == 0) return;
+        const uint32_t c = (uint32_t) lane < n_flush ? pk_c[lane] : 0u;
+        const uint32_t base = (uint32_t) __shfl((int) fl_base, (int) c);
+        const uint32_t slot = (uint32_t) __shfl((int) my_col_slot, (int) c);
+        if ((uint32_t) lane < n_flush) {
+            const uint32_t at = base + pk_k[lane];
+            if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = ((uint64_t) pk_v[lane] << 32) | pk_r[lane];
+        }
+        n_flush = 0;
+        wave_fence();
+    };
+
     rows_of(0, a_cur);
     a_nxt[0] = a_cur[0];
     a_nxt[1] = a_cur[1];
@@ -268,6 +317,35 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
             bf16x8 bfr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8, sb[j * 64]);
+#if GM_READS_UPFRONT
+            // all twelve fragment reads of the K-step are issued before its first MFMA: the LDS latency is paid once per
+            // K-step, the later fragments arrive under the earlier blocks' MFMAs (counted lgkmcnt waits by the compiler)
+            bf16x8 afr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) afr[i] = __builtin_bit_cast(bf16x8, sa[i * 64]);
+#if GM_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[j], acc[i][j], 0, 0, 0);
+#if GM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#if GM_SCHED
+            // emitted order: the four B fragments and two A fragments, then per row block its four MFMAs and the read of
+            // the A fragment two blocks ahead (the compiler's own order waits for LDS four times per K-step)
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int n = 0; n < 6; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#endif
+#else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 bf16x8 afr[4];
@@ -279,6 +357,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
                     for (int j = 0; j < 4; ++j)
                         acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
             }
+#endif
         }
         a_cur[0] = a_nxt[0];
         a_cur[1] = a_nxt[1];
@@ -291,6 +370,12 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
             if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = make_key(v, g_rank ? g_rank[row] : (uint32_t) row);
         };
         if (!generic) {
+            // Candidates are PARKED in LDS while the tile's results are looked through (no atomic in there: a returning
+            // global atomic per candidate would stall the wave a microsecond or two, eight times per tile).  Afterwards ONE
+            // wave instruction reserves room for all of them (lane c: the candidates of column c), and the keys are stored
+            // at the start of the NEXT tile's epilogue, when that atomic has long returned.
+            flush_store();
+            n_park = 0;
             float tr[8][4];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -300,48 +385,48 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
             float cs[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) cs[j] = METRIC == M_COSINE ? colc[wn * 64 + j * 16 + li].y : 0.0f;
-            // first the wave-wide question "any candidate at all?": the largest acc - (what it must reach) of the lane,
-            // two VALU operations per pair and no lane masks (a NaN row threshold drops out of fmaxf)
-            float best = -__builtin_inff();
+            // one pass over the 32 result blocks: the block's largest acc - (what it must reach) in 8 VALU operations (a NaN
+            // row threshold drops out of fmaxf), one ballot, and only a block that holds a candidate (~8 of a wave-tile's
+            // 8192 pairs are) looks at its four values again
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+                    float sl[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if constexpr (METRIC == M_COSINE) best = fmaxf(best, fmaf(-cs[j], tr[i][r], acc[i][j][r]));
-                        else best = fmaxf(best, acc[i][j][r] - tr[i][r]);
+                        if constexpr (METRIC == M_COSINE) sl[r] = fmaf(-cs[j], tr[i][r], acc[i][j][r]);
+                        else sl[r] = acc[i][j][r] - tr[i][r];
                     }
-            const uint64_t any = __ballot(best >= 0.0f);
-            if (any) {                                                         // wave-uniform, rare: ~1 survivor per 5000 pairs
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bool c[4];
-                        bool hit = false;
+                    const float best = fmaxf(fmaxf(sl[0], sl[1]), fmaxf(sl[2], sl[3]));
+                    if (__ballot(best >= 0.0f)) {
+                        const float4 cc = colc[wn * 64 + j * 16 + li];
+                        const uint32_t slot = __float_as_uint(cc.w);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            if constexpr (METRIC == M_COSINE) c[r] = acc[i][j][r] >= cs[j] * tr[i][r];
-                            else c[r] = acc[i][j][r] >= tr[i][r];
-                            hit |= c[r];
-                        }
-                        if (__ballot(hit)) {
-                            const float4 cc = colc[wn * 64 + j * 16 + li];
-                            const uint32_t slot = __float_as_uint(cc.w);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (c[r]) {
-                                    const int32_t row = ridx[i * 16 + kq * 4 + r];
-                                    float v;
-                                    if constexpr (METRIC == M_L2) v = fmaf(-2.0f, acc[i][j][r] - cc.x, 2.0f * tr[i][r] + cc.z);
-                                    else if constexpr (METRIC == M_IP) v = -(acc[i][j][r] - cc.x);
-                                    else v = 1.0f - acc[i][j][r] * rsqrtf(tr[i][r] * tr[i][r] * cc.z);
-                                    append(slot, v, row);
-                                }
+                            const bool c = sl[r] >= 0.0f;
+                            const uint64_t cm = __ballot(c);
+                            if (!cm) continue;
+                            const int32_t row = ridx[i * 16 + kq * 4 + r];
+                            float v;
+                            if constexpr (METRIC == M_L2) v = fmaf(-2.0f, acc[i][j][r] - cc.x, 2.0f * tr[i][r] + cc.z);
+                            else if constexpr (METRIC == M_IP) v = -(acc[i][j][r] - cc.x);
+                            else v = 1.0f - acc[i][j][r] * rsqrtf(tr[i][r] * tr[i][r] * cc.z);
+                            const uint32_t at = n_park + __builtin_amdgcn_mbcnt_hi((uint32_t) (cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) cm, 0u));
+                            if (c) {
+                                if (at < (uint32_t) GM_PARK) {
+                                    pk_v[at] = mono_bits(v);
+                                    pk_r[at] = g_rank ? g_rank[row] : (uint32_t) row;
+                                    pk_c[at] = (uint32_t) (j * 16 + li);
+                                } else
+                                    append(slot, v, row);                      // a burst beyond the parking area: directly
+                            }
+                            n_park += (uint32_t) __popcll(cm);
                         }
                     }
-            }
+                }
+            if (n_park > (uint32_t) GM_PARK) n_park = GM_PARK;
+            flush_reserve();
         } else {
             // generic: the screening value of every valid pair.  SAMPLE keeps one minimum per query column and wave-tile
             // (128 rows); an open threshold admits every valid pair (only planned for filters that fit the buffer)
@@ -382,6 +467,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
             }
         }
     }
+    if (!generic) flush_store();
     // the three stages still in flight write LDS: they must have landed before the workgroup gives its LDS back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
