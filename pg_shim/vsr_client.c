@@ -171,7 +171,7 @@ int
 vsr_sc_corpus_load(vsr_sc_conn * c, uint64_t key, uint64_t version, const float *rows, int64_t n, int dim, const int64_t *blk,
 				   const int32_t *doc, vsr_sc_corpus_info * out)
 {
-	vsr_sc_load l;
+	vsr_sc_load_req l;
 	part		ps[4];
 	vsr_sc_reply rep;
 
@@ -197,7 +197,7 @@ int
 vsr_sc_rbac_load(vsr_sc_conn * c, uint64_t handle, const int32_t *ur_user, const int32_t *ur_role, int64_t n_ur,
 				 const int32_t *pa_role, const int32_t *pa_doc, int64_t n_pa)
 {
-	vsr_sc_rbac r = {handle, n_ur, n_pa};
+	vsr_sc_rbac_req r = {handle, n_ur, n_pa};
 	part		ps[5] = {{&r, sizeof(r)}, {ur_user, sizeof(int32_t) * (size_t) n_ur}, {ur_role, sizeof(int32_t) * (size_t) n_ur},
 	{pa_role, sizeof(int32_t) * (size_t) n_pa}, {pa_doc, sizeof(int32_t) * (size_t) n_pa}};
 	vsr_sc_reply rep;
@@ -207,7 +207,7 @@ vsr_sc_rbac_load(vsr_sc_conn * c, uint64_t handle, const int32_t *ur_user, const
 }
 
 int
-vsr_sc_search(vsr_sc_conn * c, const vsr_sc_search * req, const float *queries, int32_t *counts, int64_t *rows, int64_t *blk,
+vsr_sc_search(vsr_sc_conn * c, const vsr_sc_search_req * req, const float *queries, int32_t *counts, int64_t *rows, int64_t *blk,
 			  float *dist)
 {
 	part		ps[2] = {{req, sizeof(*req)}, {queries, sizeof(float) * (size_t) req->nq * (size_t) req->dim}};
@@ -218,8 +218,9 @@ vsr_sc_search(vsr_sc_conn * c, const vsr_sc_search * req, const float *queries, 
 
 	if (rc != 0)
 		return rc < 0 ? rc : (drain(c, rep.payload_bytes), rc);
-	if (rep.payload_bytes != sizeof(res) + (size_t) req->nq * 4 + nk * 20 || io_all(c->fd, &res, sizeof(res), 0) ||
-		res.nq != req->nq || res.k != req->k || io_all(c->fd, counts, (size_t) req->nq * 4, 0) || io_all(c->fd, rows, nk * 8, 0) ||
+	if (rep.payload_bytes != sizeof(res) + VSR_SC_COUNTS_BYTES(req->nq) + nk * 20 || io_all(c->fd, &res, sizeof(res), 0) ||
+		res.nq != req->nq || res.k != req->k || io_all(c->fd, counts, (size_t) req->nq * 4, 0) ||
+		drain(c, VSR_SC_COUNTS_BYTES(req->nq) - (size_t) req->nq * 4) || io_all(c->fd, rows, nk * 8, 0) ||
 		io_all(c->fd, blk, nk * 8, 0) || io_all(c->fd, dist, nk * 4, 0))
 	{
 		snprintf(c->err, sizeof(c->err), "vsrbac sidecar: malformed search reply");
@@ -229,7 +230,7 @@ vsr_sc_search(vsr_sc_conn * c, const vsr_sc_search * req, const float *queries, 
 }
 
 int
-vsr_sc_hnsw_load(vsr_sc_conn * c, const vsr_sc_hnsw * req, int unused, const int32_t *level, const int32_t *nbr0,
+vsr_sc_hnsw_load(vsr_sc_conn * c, const vsr_sc_hnsw_req * req, int unused, const int32_t *level, const int32_t *nbr0,
 				 const int32_t *tid_count, const int64_t *tids, const int32_t *up_slot, const int32_t *up_nbr)
 {
 	size_t		ne = (size_t) req->n_elem;
@@ -244,7 +245,7 @@ vsr_sc_hnsw_load(vsr_sc_conn * c, const vsr_sc_hnsw * req, int unused, const int
 }
 
 int
-vsr_sc_ivf_load(vsr_sc_conn * c, const vsr_sc_ivf * req, int dim, int64_t nrows, const float *centers, const int32_t *row_list)
+vsr_sc_ivf_load(vsr_sc_conn * c, const vsr_sc_ivf_req * req, int dim, int64_t nrows, const float *centers, const int32_t *row_list)
 {
 	part		ps[3] = {{req, sizeof(*req)}, {centers, sizeof(float) * (size_t) req->lists * (size_t) dim},
 	{row_list, sizeof(int32_t) * (size_t) nrows}};

@@ -63,12 +63,25 @@ hnswgettuple(IndexScanDesc scan, ScanDirection dir)
 		return true;
 	if (hnsw_iterative_scan != HNSW_ITERATIVE_SCAN_OFF && so->nresults > 0 && so->nresults < VSR_MAX_K)
 	{
-		/* iterative scan: the filter above the index discarded rows and the executor wants more (:227-276) */
+		/*
+		 * Iterative scan: the filter above the index discarded rows and the executor wants more (:227-276).  pgvector
+		 * resumes its graph walk from the candidates it had discarded; here the search is re-run with twice the width
+		 * and what was handed out already is skipped -- the exact search returns a prefix-stable total order, and the
+		 * index-faithful walk with a wider beam contains the narrower beam's answer up to the reference's own
+		 * "relaxed order" tolerance (hnsw.iterative_scan = relaxed_order, hnsw.c:90-92).  Bounded by
+		 * hnsw.max_scan_tuples (:232-236) and by HNSW_MAX_EF_SEARCH.
+		 */
 		int			had = so->nresults;
+		int			wider = Min(2 * had, VSR_MAX_K);
 
+		if (had >= hnsw_max_scan_tuples)
+			return false;
 		MemoryContextReset(so->tmpCtx);
-		VsrRunSearch(scan, so, Min(2 * had, VSR_MAX_K));
-		so->next = Min(had, so->nresults);	/* results are a prefix-stable total order: skip what was returned */
+		if (vsr_pg_index_faithful)
+			VsrRunIndexSearch(scan, so, true, Min(wider, HNSW_MAX_EF_SEARCH));
+		else
+			VsrRunSearch(scan, so, wider);
+		so->next = Min(had, so->nresults);
 		return VsrNextTuple(scan, so);
 	}
 	return false;

@@ -220,7 +220,22 @@ VsrLoadHnswGraph(Relation index, VsrPgCorpus * pc)
 		UnlockReleaseBuffer(buf);
 	}
 
-	if (entry >= 0)
+	if (entry >= 0 && pc->sc_handle != 0)
+	{
+		vsr_sc_hnsw_req req;
+
+		memset(&req, 0, sizeof(req));
+		req.handle = pc->sc_handle;
+		req.m = m;
+		req.n_elem = n_elem;
+		req.entry = entry;
+		req.n_upper = n_upper;
+		req.max_level = max_level;
+		if (vsr_sc_hnsw_load(VsrSidecar(), &req, 0, level, nbr0, tid_count, tids, up_slot, up_nbr) != 0)
+			ereport(ERROR, (errcode(ERRCODE_EXTERNAL_ROUTINE_EXCEPTION), errmsg("%s", vsr_sc_error(VsrSidecar()))));
+		pc->sc_has_hnsw = true;
+	}
+	else if (entry >= 0)
 		VsrCheck(vsr_hnsw_load(pc->corpus, m, n_elem, entry, level, nbr0, tid_count, tids, up_slot, up_nbr, n_upper, max_level,
 							   &graph));
 	hash_destroy(elems);
@@ -306,7 +321,19 @@ VsrLoadIvfLists(Relation index, VsrPgCorpus * pc)
 			UnlockReleaseBuffer(buf);
 		}
 
-	VsrCheck(vsr_ivf_load(pc->corpus, centers, nl, row_list, &ivf));
+	if (pc->sc_handle != 0)
+	{
+		vsr_sc_ivf_req req;
+
+		memset(&req, 0, sizeof(req));
+		req.handle = pc->sc_handle;
+		req.lists = nl;
+		if (vsr_sc_ivf_load(VsrSidecar(), &req, dim, pc->nrows, centers, row_list) != 0)
+			ereport(ERROR, (errcode(ERRCODE_EXTERNAL_ROUTINE_EXCEPTION), errmsg("%s", vsr_sc_error(VsrSidecar()))));
+		pc->sc_has_ivf = true;
+	}
+	else
+		VsrCheck(vsr_ivf_load(pc->corpus, centers, nl, row_list, &ivf));
 	hash_destroy(tidrows);
 	pfree(centers);
 	pfree(start);
@@ -324,8 +351,9 @@ VsrRunIndexSearch(IndexScanDesc scan, VsrPgScanOpaque so, bool is_hnsw, int ef_o
 	VsrPgCorpus *pc = so->pc;
 	MemoryContext old = MemoryContextSwitchTo(so->tmpCtx);
 	Vector	   *q;
-	vsr_filter *filter;
-	int			k = is_hnsw ? ef_or_probes : VSR_MAX_K;	/* an hnsw scan can return ef_search items (hnswscan.c:44) */
+	const vsr_filter *filter = NULL;
+	/* an hnsw scan can return ef_search items (hnswscan.c:44); ef_search goes to 5000, a result list to VSR_MAX_K */
+	int			k = is_hnsw ? Min(ef_or_probes, VSR_MAX_K) : VSR_MAX_K;
 	int64	   *blk = palloc(sizeof(int64) * k),
 			   *rowidx = palloc(sizeof(int64) * k);
 	float	   *dist = palloc(sizeof(float) * k);
@@ -334,6 +362,33 @@ VsrRunIndexSearch(IndexScanDesc scan, VsrPgScanOpaque so, bool is_hnsw, int ef_o
 	if (scan->orderByData == NULL)
 		elog(ERROR, "cannot scan %s index without order", is_hnsw ? "hnsw" : "ivfflat");
 	q = DatumGetVector(scan->orderByData->sk_argument);
+	if (pc->sc_handle != 0)
+	{
+		/* sidecar mode: the graph / lists are loaded into the sidecar once (by whichever backend comes first) */
+		vsr_sc_search_req req;
+
+		if (is_hnsw ? !pc->sc_has_hnsw : !pc->sc_has_ivf)
+		{
+			if (is_hnsw)
+				(void) VsrLoadHnswGraph(scan->indexRelation, pc);
+			else
+				(void) VsrLoadIvfLists(scan->indexRelation, pc);
+		}
+		memset(&req, 0, sizeof(req));
+		req.handle = pc->sc_handle;
+		req.nq = 1;
+		req.dim = q->dim;
+		req.k = k;
+		req.metric = VsrMetricOf(scan->indexRelation);
+		req.filter_mode = (vsr_pg_mode == VSR_PG_MODE_OFF || !pc->has_rbac || superuser()) ? -1 :
+			vsr_pg_mode == VSR_PG_MODE_PREFILTER ? VSR_FILTER_RANGES : VSR_FILTER_BITMAP;
+		req.user_id = VsrCurrentUserId();
+		req.index = (is_hnsw ? pc->sc_has_hnsw : pc->sc_has_ivf) ? (is_hnsw ? 1 : 2) : 0;	/* empty index: the exact search */
+		req.param = ef_or_probes;
+		if (vsr_sc_search(VsrSidecar(), &req, q->x, &count, rowidx, blk, dist) != 0)
+			ereport(ERROR, (errcode(ERRCODE_EXTERNAL_ROUTINE_EXCEPTION), errmsg("%s", vsr_sc_error(VsrSidecar()))));
+		goto emit;
+	}
 	filter = VsrFilterForCurrentUser(pc);
 	if (is_hnsw)
 	{
@@ -350,6 +405,7 @@ VsrRunIndexSearch(IndexScanDesc scan, VsrPgScanOpaque so, bool is_hnsw, int ef_o
 		VsrCheck(vsr_ivf_search(pc->ivf, q->x, 1, q->dim, k, ef_or_probes, VsrMetricOf(scan->indexRelation),
 								filter ? &filter : NULL, blk, NULL, rowidx, dist, &count));
 	}
+emit:
 	so->result_tids = palloc(sizeof(ItemPointerData) * Max(count, 1));
 	for (int i = 0; i < count; i++)
 		so->result_tids[i] = pc->tids[rowidx[i]];

@@ -55,8 +55,23 @@ ivfflatgettuple(IndexScanDesc scan, ScanDirection dir)
 		else
 			VsrRunSearch(scan, so, VSR_MAX_K);
 		so->first = false;
+		so->probes_used = ivfflat_probes;
 	}
-	return VsrNextTuple(scan, so);
+	if (VsrNextTuple(scan, so))
+		return true;
+	if (vsr_pg_index_faithful && ivfflat_iterative_scan != IVFFLAT_ITERATIVE_SCAN_OFF && so->nresults > 0 &&
+		so->probes_used < Min(ivfflat_max_probes, IVFFLAT_MAX_LISTS))
+	{
+		/* ivfflat.iterative_scan (ivfscan.c:292-337): the probed lists ran dry, probe the next batch of lists */
+		int			had = so->nresults;
+
+		so->probes_used = Min(2 * so->probes_used, Min(ivfflat_max_probes, IVFFLAT_MAX_LISTS));
+		MemoryContextReset(so->tmpCtx);
+		VsrRunIndexSearch(scan, so, false, so->probes_used);
+		so->next = Min(had, so->nresults);
+		return VsrNextTuple(scan, so);
+	}
+	return false;
 }
 
 void

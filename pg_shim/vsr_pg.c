@@ -12,6 +12,8 @@
 #include "access/heapam.h"
 #include "access/tableam.h"
 #include "catalog/index.h"
+#include "catalog/namespace.h"
+#include "storage/bufmgr.h"
 #include "executor/spi.h"
 #include "executor/tuptable.h"
 #include "miscadmin.h"
@@ -19,6 +21,7 @@
 #include "utils/builtins.h"
 #include "utils/guc.h"
 #include "utils/hsearch.h"
+#include "utils/inval.h"
 #include "utils/lsyscache.h"
 #include "utils/memutils.h"
 #include "utils/snapmgr.h"
@@ -28,6 +31,9 @@
 int			vsr_pg_device = 0;
 int			vsr_pg_mode = VSR_PG_MODE_POSTFILTER;
 bool		vsr_pg_index_faithful = false;
+char	   *vsr_pg_sidecar = NULL;
+static int	vsr_pg_epoch = 0;	/* GUC vsrbac.epoch: any change drops every cached corpus (an explicit refresh) */
+static vsr_sc_conn *sidecar_conn = NULL;
 
 static const struct config_enum_entry vsr_pg_mode_options[] = {
 	{"off", VSR_PG_MODE_OFF, false},
@@ -77,6 +83,124 @@ vsr_pg_shutdown(int code, Datum arg)
 		(void) vsr_close(backend_ctx);
 		backend_ctx = NULL;
 	}
+	if (sidecar_conn != NULL)
+	{
+		vsr_sc_close(sidecar_conn);	/* the sidecar keeps the corpora: that is what it is for */
+		sidecar_conn = NULL;
+	}
+}
+
+vsr_sc_conn *
+VsrSidecar(void)
+{
+	char		err[256];
+
+	if (vsr_pg_sidecar == NULL || vsr_pg_sidecar[0] == '\0')
+		return NULL;
+	if (sidecar_conn == NULL)
+	{
+		sidecar_conn = vsr_sc_connect(vsr_pg_sidecar, err, sizeof(err));
+		if (sidecar_conn == NULL)
+			ereport(ERROR, (errcode(ERRCODE_CONNECTION_FAILURE), errmsg("%s", err)));
+		on_proc_exit(vsr_pg_shutdown, (Datum) 0);
+	}
+	return sidecar_conn;
+}
+
+/* sidecar calls report through the same channel as library calls */
+static void
+VsrScCheck(int status)
+{
+	if (status == 0)
+		return;
+	if (status < 0)
+	{
+		/* the connection is gone: forget it, the next scan reconnects and finds (or reloads) the corpus */
+		char		msg[256];
+
+		snprintf(msg, sizeof(msg), "%s", vsr_sc_error(sidecar_conn));
+		vsr_sc_close(sidecar_conn);
+		sidecar_conn = NULL;
+		ereport(ERROR, (errcode(ERRCODE_CONNECTION_FAILURE), errmsg("%s", msg)));
+	}
+	ereport(ERROR,
+			(errcode(status == VSR_ERR_DIM_MISMATCH ? ERRCODE_DATA_EXCEPTION :
+					 status == VSR_ERR_OOM ? ERRCODE_OUT_OF_MEMORY : ERRCODE_EXTERNAL_ROUTINE_EXCEPTION),
+			 errmsg("%s", vsr_sc_error(sidecar_conn))));
+}
+
+/* drop what this backend holds of a cached corpus (the entry stays, marked empty) */
+static void
+vsr_pg_forget(VsrPgCorpus * pc)
+{
+	if (pc->graph != NULL)
+		(void) vsr_hnsw_free(pc->graph);
+	if (pc->ivf != NULL)
+		(void) vsr_ivf_free(pc->ivf);
+	if (pc->corpus != NULL)
+		(void) vsr_corpus_free(pc->corpus);
+	if (pc->tids != NULL)
+		pfree(pc->tids);
+	pc->graph = NULL;
+	pc->ivf = NULL;
+	pc->corpus = NULL;
+	pc->tids = NULL;
+	pc->sc_handle = 0;
+	pc->sc_has_hnsw = pc->sc_has_ivf = false;
+	pc->stale = false;
+}
+
+/*
+ * Relcache invalidation (DDL, VACUUM, TRUNCATE, ANALYZE, CREATE INDEX on the heap or on an RBAC table): the cached copy
+ * may no longer match; it is rebuilt by the next scan.  Plain INSERT / UPDATE / DELETE send no relcache invalidation:
+ * those are caught by the block-count half of the version fingerprint when they extend a relation, and otherwise by
+ * vsrbac.epoch ("Freshness").
+ */
+static void
+vsr_pg_relcache_cb(Datum arg, Oid relid)
+{
+	HASH_SEQ_STATUS seq;
+	VsrPgCorpus *pc;
+
+	(void) arg;
+	if (corpus_cache == NULL)
+		return;
+	hash_seq_init(&seq, corpus_cache);
+	while ((pc = (VsrPgCorpus *) hash_seq_search(&seq)) != NULL)
+		if (relid == InvalidOid || relid == pc->indexoid || relid == pc->heapoid || relid == pc->rbac_oids[0] ||
+			relid == pc->rbac_oids[1])
+			pc->stale = true;
+}
+
+/* what a cached copy was built from: relfilenode and size of the heap and of the two RBAC tables */
+static uint64
+vsr_pg_fingerprint(Relation heap, Oid *rbac_oids)
+{
+	uint64		h = UINT64CONST(0xcbf29ce484222325);
+	const char *names[2] = {"userroles", "permissionassignment"};
+
+#define MIX(v) do { h ^= (uint64) (v); h *= UINT64CONST(0x100000001b3); } while (0)
+	MIX(RelationGetRelid(heap));
+	MIX(heap->rd_rel->relfilenode);
+	MIX(RelationGetNumberOfBlocks(heap));
+	for (int i = 0; i < 2; i++)
+	{
+		Oid			oid = RelnameGetRelid(names[i]);
+
+		rbac_oids[i] = oid;
+		if (OidIsValid(oid))
+		{
+			Relation	r = table_open(oid, AccessShareLock);
+
+			MIX(r->rd_rel->relfilenode);
+			MIX(RelationGetNumberOfBlocks(r));
+			table_close(r, AccessShareLock);
+		}
+		else
+			MIX(0);
+	}
+#undef MIX
+	return h;
 }
 
 vsr_ctx *
@@ -158,6 +282,11 @@ VsrCorpusForIndex(Relation index)
 	Oid			indexoid = RelationGetRelid(index);
 	bool		found;
 	VsrPgCorpus *pc;
+	Relation	heap;
+	Oid			rbac_oids[2];
+	uint64		version;
+	vsr_sc_conn *sc = VsrSidecar();
+	const uint64 sc_key = ((uint64) MyDatabaseId << 32) | (uint64) indexoid;
 
 	if (corpus_cache == NULL)
 	{
@@ -170,19 +299,57 @@ VsrCorpusForIndex(Relation index)
 		corpus_cache = hash_create("vsrbac corpora", 16, &hc, HASH_ELEM | HASH_BLOBS | HASH_CONTEXT);
 	}
 	pc = hash_search(corpus_cache, &indexoid, HASH_ENTER, &found);
-	if (found && pc->corpus != NULL)
-		return pc;
-	pc->corpus = NULL;
-	pc->graph = NULL;			/* loaded on first index-faithful scan (vsr_indexload.c) */
-	pc->ivf = NULL;
-
+	if (!found)
 	{
-		Relation	heap = table_open(index->rd_index->indrelid, AccessShareLock);
+		memset(((char *) pc) + sizeof(Oid), 0, sizeof(VsrPgCorpus) - sizeof(Oid));
+		pc->indexoid = indexoid;
+	}
+
+	/* is the copy we (or the sidecar) hold still the table the current snapshot sees? */
+	heap = table_open(index->rd_index->indrelid, AccessShareLock);
+	version = vsr_pg_fingerprint(heap, rbac_oids);
+	if (found && (pc->corpus != NULL || pc->sc_handle != 0) && !pc->stale && pc->version == version && pc->epoch == vsr_pg_epoch)
+	{
+		table_close(heap, AccessShareLock);
+		return pc;
+	}
+	vsr_pg_forget(pc);
+	pc->heapoid = RelationGetRelid(heap);
+	pc->rbac_oids[0] = rbac_oids[0];
+	pc->rbac_oids[1] = rbac_oids[1];
+	pc->version = version ^ (uint64) vsr_pg_epoch;
+	pc->epoch = vsr_pg_epoch;
+
+	/* sidecar mode: another backend may have loaded this very version already */
+	if (sc != NULL)
+	{
+		vsr_sc_corpus_info info;
+		int			rc = vsr_sc_corpus_lookup(sc, sc_key, pc->version, &info);
+
+		if (rc == 0)
+		{
+			pc->sc_handle = info.handle;
+			pc->dim = info.dim;
+			pc->nrows = info.nrows;
+			pc->has_rbac = info.has_rbac != 0;
+			pc->sc_has_hnsw = info.has_hnsw != 0;
+			pc->sc_has_ivf = info.has_ivf != 0;
+		}
+		else if (rc != VSR_SC_NOTFOUND)
+			VsrScCheck(rc);
+	}
+
+	/*
+	 * The heap in scan order under the active snapshot: the TIDs are needed by every backend (row index -> heap TID), the
+	 * vectors only when somebody has to load the corpus.
+	 */
+	{
 		AttrNumber	vec_att = index->rd_index->indkey.values[0];
 		AttrNumber	blk_att = heap_attno(heap, "block_id");
 		AttrNumber	doc_att = heap_attno(heap, "document_id");
 		TableScanDesc hs = table_beginscan(heap, GetActiveSnapshot(), 0, NULL);
 		TupleTableSlot *slot = table_slot_create(heap, NULL);
+		const bool	need_rows = sc == NULL || pc->sc_handle == 0;
 		int64		cap = 1 << 16,
 					n = 0;
 		int			dim = 0;
@@ -203,17 +370,20 @@ VsrCorpusForIndex(Relation index)
 			if (dim == 0)
 			{
 				dim = v->dim;
-				rows = MemoryContextAllocHuge(CurrentMemoryContext, sizeof(float) * (Size) cap * dim);
+				if (need_rows)
+					rows = MemoryContextAllocHuge(CurrentMemoryContext, sizeof(float) * (Size) cap * dim);
 			}
 			if (n == cap)
 			{
 				cap *= 2;
-				rows = repalloc_huge(rows, sizeof(float) * (Size) cap * dim);
+				if (need_rows)
+					rows = repalloc_huge(rows, sizeof(float) * (Size) cap * dim);
 				blk = repalloc_huge(blk, sizeof(int64) * cap);
 				doc = repalloc_huge(doc, sizeof(int32) * cap);
 				tids = repalloc_huge(tids, sizeof(ItemPointerData) * cap);
 			}
-			memcpy(rows + (Size) n * dim, v->x, sizeof(float) * dim);
+			if (need_rows)
+				memcpy(rows + (Size) n * dim, v->x, sizeof(float) * dim);
 			blk[n] = blk_att ? DatumGetInt64(slot_getattr(slot, blk_att, &isnull)) : n;
 			doc[n] = doc_att ? DatumGetInt32(slot_getattr(slot, doc_att, &isnull)) : 0;
 			tids[n] = slot->tts_tid;
@@ -223,22 +393,41 @@ VsrCorpusForIndex(Relation index)
 		table_endscan(hs);
 		table_close(heap, AccessShareLock);
 
-		pc->indexoid = indexoid;
+		pc->tids = tids;
+		if (pc->sc_handle != 0 && n != pc->nrows)
+		{
+			/* the resident copy was loaded under another snapshot of the same files: replace it */
+			VsrScCheck(vsr_sc_corpus_drop(sc, sc_key));
+			vsr_pg_forget(pc);
+			pfree(blk);
+			pfree(doc);
+			return VsrCorpusForIndex(index);
+		}
 		pc->dim = dim;
 		pc->nrows = n;
-		pc->tids = tids;
-		pc->has_rbac = false;
-		pc->corpus = NULL;
-		VsrCheck(vsr_corpus_load(VsrBackendContext(), rows, n, dim > 0 ? dim : 1, blk_att ? blk : NULL, doc_att ? doc : NULL, 0,
-								 &pc->corpus));
-		if (rows)
-			pfree(rows);
+		if (need_rows)
+		{
+			pc->has_rbac = false;
+			if (sc != NULL)
+			{
+				vsr_sc_corpus_info info;
+
+				VsrScCheck(vsr_sc_corpus_load(sc, sc_key, pc->version, rows, n, dim > 0 ? dim : 1, blk_att ? blk : NULL,
+											  doc_att ? doc : NULL, &info));
+				pc->sc_handle = info.handle;
+			}
+			else
+				VsrCheck(vsr_corpus_load(VsrBackendContext(), rows, n, dim > 0 ? dim : 1, blk_att ? blk : NULL, doc_att ? doc : NULL,
+										 0, &pc->corpus));
+			if (rows)
+				pfree(rows);
+		}
 		pfree(blk);
 		pfree(doc);
 	}
 
 	/* RBAC tables, when the schema of the reference is present and the heap carries document ids */
-	if (SPI_connect() == SPI_OK_CONNECT)
+	if (!pc->has_rbac && OidIsValid(pc->rbac_oids[0]) && OidIsValid(pc->rbac_oids[1]) && SPI_connect() == SPI_OK_CONNECT)
 	{
 		int32	   *uu = NULL, *ur = NULL, *pr = NULL, *pd = NULL;
 		int64		n_ur = load_pairs("SELECT user_id, role_id FROM userroles", &uu, &ur, CurrentMemoryContext);
@@ -246,7 +435,10 @@ VsrCorpusForIndex(Relation index)
 
 		if (n_ur >= 0 && n_pa >= 0)
 		{
-			VsrCheck(vsr_rbac_load(pc->corpus, uu, ur, n_ur, pr, pd, n_pa));
+			if (sc != NULL)
+				VsrScCheck(vsr_sc_rbac_load(sc, pc->sc_handle, uu, ur, n_ur, pr, pd, n_pa));
+			else
+				VsrCheck(vsr_rbac_load(pc->corpus, uu, ur, n_ur, pr, pd, n_pa));
 			pc->has_rbac = true;
 		}
 		SPI_finish();
@@ -295,9 +487,27 @@ VsrRunSearch(IndexScanDesc scan, VsrPgScanOpaque so, int k_hint)
 	if (q->dim != pc->dim)
 		ereport(ERROR, (errcode(ERRCODE_DATA_EXCEPTION),
 						errmsg("different vector dimensions %d and %d", pc->dim, q->dim)));
-	filter = VsrFilterForCurrentUser(pc);
-	VsrCheck(vsr_search(pc->corpus, q->x, 1, q->dim, k, VsrMetricOf(scan->indexRelation), filter ? &filter : NULL,
-						blk, NULL, rowidx, dist, &count));
+	if (pc->sc_handle != 0)
+	{
+		vsr_sc_search_req req;
+
+		memset(&req, 0, sizeof(req));
+		req.handle = pc->sc_handle;
+		req.nq = 1;
+		req.dim = q->dim;
+		req.k = k;
+		req.metric = VsrMetricOf(scan->indexRelation);
+		req.filter_mode = (vsr_pg_mode == VSR_PG_MODE_OFF || !pc->has_rbac || superuser()) ? -1 :
+			vsr_pg_mode == VSR_PG_MODE_PREFILTER ? VSR_FILTER_RANGES : VSR_FILTER_BITMAP;
+		req.user_id = VsrCurrentUserId();
+		VsrScCheck(vsr_sc_search(VsrSidecar(), &req, q->x, &count, rowidx, blk, dist));
+	}
+	else
+	{
+		filter = VsrFilterForCurrentUser(pc);
+		VsrCheck(vsr_search(pc->corpus, q->x, 1, q->dim, k, VsrMetricOf(scan->indexRelation), filter ? &filter : NULL,
+							blk, NULL, rowidx, dist, &count));
+	}
 	so->result_tids = palloc(sizeof(ItemPointerData) * Max(count, 1));
 	for (int i = 0; i < count; i++)
 		so->result_tids[i] = pc->tids[rowidx[i]];
@@ -330,5 +540,14 @@ VsrPgInit(void)
 							 "Answer index scans with the index's own graph walk / list probe on the GPU (same candidates and "
 							 "recall as stock pgvector) instead of the exact filtered search", NULL, &vsr_pg_index_faithful,
 							 false, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomStringVariable("vsrbac.sidecar",
+							   "UNIX socket of the resident GPU process (pg_shim/vsr_sidecar); empty: every backend loads its own copy",
+							   "With a sidecar the corpus survives the backend: a new connection per search, as the reference harness "
+							   "makes them, costs a socket connect instead of a corpus load", &vsr_pg_sidecar, "", PGC_USERSET, 0,
+							   NULL, NULL, NULL);
+	DefineCustomIntVariable("vsrbac.epoch", "Changing this value drops every cached corpus of this backend (and, through the "
+							"version, of the sidecar): an explicit refresh after INSERT / UPDATE / DELETE", NULL,
+							&vsr_pg_epoch, 0, 0, INT_MAX, PGC_USERSET, 0, NULL, NULL, NULL);
 	MarkGUCPrefixReserved("vsrbac");
+	CacheRegisterRelcacheCallback(vsr_pg_relcache_cb, (Datum) 0);
 }

@@ -27,6 +27,7 @@
 #include "utils/rel.h"
 
 #include "vsrbac.h"
+#include "vsr_sidecar.h"
 
 /* how the current user's permissions are applied (GUC vsrbac.mode) */
 typedef enum
@@ -39,11 +40,25 @@ typedef enum
 extern int	vsr_pg_device;		/* GUC vsrbac.device */
 extern int	vsr_pg_mode;		/* GUC vsrbac.mode */
 extern bool vsr_pg_index_faithful;	/* GUC vsrbac.index_faithful: reproduce the index's own answer (vsr_indexload.c) */
+extern char *vsr_pg_sidecar;	/* GUC vsrbac.sidecar: socket of the resident GPU process ("" = in-process, per backend) */
 
-/* One resident corpus per index relation, cached for the life of the backend (or of the sidecar). */
+/*
+ * One resident corpus per index relation.  In-process mode: owned by this backend (corpus / graph / ivf).  Sidecar mode
+ * (vsrbac.sidecar): owned by the sidecar and shared by every backend; this struct then only remembers its handle.
+ * `version` fingerprints what the copy was built from (heap and RBAC tables: relfilenode and block count); a scan that
+ * computes another fingerprint, a relcache invalidation of one of those relations (DDL, VACUUM, TRUNCATE, ANALYZE) or a
+ * change of vsrbac.epoch drops the copy and rebuilds it under the current snapshot.
+ */
 typedef struct VsrPgCorpus
 {
 	Oid			indexoid;
+	Oid			heapoid;
+	Oid			rbac_oids[2];		/* userroles, permissionassignment (InvalidOid: absent) */
+	uint64		version;
+	int			epoch;				/* vsrbac.epoch at load time */
+	bool		stale;				/* set by the relcache callback */
+	uint64		sc_handle;			/* sidecar mode: the sidecar's handle (0: in-process) */
+	bool		sc_has_hnsw, sc_has_ivf;
 	vsr_corpus *corpus;
 	int			dim;
 	int64		nrows;
@@ -60,6 +75,7 @@ typedef struct VsrPgScanOpaqueData
 	bool		first;
 	int			nresults;
 	int			next;
+	int			probes_used;		/* ivfflat iterative scan: lists probed so far */
 	ItemPointerData *result_tids;
 	MemoryContext tmpCtx;
 }			VsrPgScanOpaqueData;
@@ -73,6 +89,8 @@ extern int	VsrMetricOf(Relation index);	/* opclass distance proc -> VSR_METRIC_*
 extern int32 VsrCurrentUserId(void);	/* current_user::int, the reference's RLS convention */
 extern vsr_filter *VsrFilterForCurrentUser(VsrPgCorpus * pc);	/* NULL when vsrbac.mode = off or no RBAC tables */
 extern void VsrRunSearch(IndexScanDesc scan, VsrPgScanOpaque so, int k_hint);	/* fills so->result_tids */
+extern void VsrPgInit(void);	/* GUCs + invalidation callback; called by _PG_init (vsr_init.c) */
+extern vsr_sc_conn *VsrSidecar(void);	/* connection of this backend to the sidecar, or NULL in in-process mode */
 extern bool VsrNextTuple(IndexScanDesc scan, VsrPgScanOpaque so);
 
 /* vsr_indexload.c */

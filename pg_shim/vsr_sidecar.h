@@ -26,11 +26,11 @@ typedef enum
 {
 	VSR_SC_PING = 1,
 	VSR_SC_CORPUS_LOOKUP,			/* vsr_sc_key                         -> vsr_sc_corpus_info */
-	VSR_SC_CORPUS_LOAD,				/* vsr_sc_load + rows [+ blk] [+ doc] -> vsr_sc_corpus_info   (vsr_corpus_load) */
-	VSR_SC_RBAC_LOAD,				/* vsr_sc_rbac + four int32 arrays    -> (none)               (vsr_rbac_load) */
-	VSR_SC_SEARCH,					/* vsr_sc_search + queries            -> vsr_sc_result        (vsr_search, filter = user) */
-	VSR_SC_HNSW_LOAD,				/* vsr_sc_hnsw + graph arrays         -> (none)               (vsr_hnsw_load) */
-	VSR_SC_IVF_LOAD,				/* vsr_sc_ivf + centres + row_list    -> (none)               (vsr_ivf_load) */
+	VSR_SC_CORPUS_LOAD,				/* vsr_sc_load_req + rows [+ blk] [+ doc] -> vsr_sc_corpus_info   (vsr_corpus_load) */
+	VSR_SC_RBAC_LOAD,				/* vsr_sc_rbac_req + four int32 arrays    -> (none)               (vsr_rbac_load) */
+	VSR_SC_SEARCH,					/* vsr_sc_search_req + queries            -> vsr_sc_result        (vsr_search, filter = user) */
+	VSR_SC_HNSW_LOAD,				/* vsr_sc_hnsw_req + graph arrays         -> (none)               (vsr_hnsw_load) */
+	VSR_SC_IVF_LOAD,				/* vsr_sc_ivf_req + centres + row_list    -> (none)               (vsr_ivf_load) */
 	VSR_SC_CORPUS_DROP,				/* vsr_sc_key                         -> (none) */
 	VSR_SC_SHUTDOWN
 }			vsr_sc_op;
@@ -75,14 +75,14 @@ typedef struct
 	int32_t		has_blk;			/* payload: float rows[nrows*dim], then int64 blk[nrows] (has_blk), then int32 doc[nrows] (has_doc) */
 	int32_t		has_doc;
 	int32_t		pad;
-}			vsr_sc_load;
+}			vsr_sc_load_req;
 
 typedef struct
 {
 	uint64_t	handle;
 	int64_t		n_user_roles;		/* payload: int32 ur_user[], ur_role[], then int32 pa_role[], pa_doc[] */
 	int64_t		n_permissions;
-}			vsr_sc_rbac;
+}			vsr_sc_rbac_req;
 
 typedef struct
 {
@@ -95,13 +95,15 @@ typedef struct
 	int32_t		user_id;
 	int32_t		index;				/* 0: exact search; 1: hnsw graph walk (param = ef_search); 2: ivfflat probe (param = probes) */
 	int32_t		param;				/* payload: float queries[nq*dim] */
-}			vsr_sc_search;
+}			vsr_sc_search_req;
 
-typedef struct						/* reply payload: this header, then int32 counts[nq], int64 rows[nq*k], int64 blk[nq*k], float dist[nq*k] */
+typedef struct						/* reply payload: this header, then int32 counts[nq] (padded to 8 bytes), int64 rows[nq*k],
+									 * int64 blk[nq*k], float dist[nq*k] */
 {
 	int32_t		nq;
 	int32_t		k;
 }			vsr_sc_result;
+#define VSR_SC_COUNTS_BYTES(nq) ((((size_t) (nq) + 1) / 2) * 8)
 
 typedef struct
 {
@@ -113,14 +115,14 @@ typedef struct
 	int32_t		max_level;
 	int32_t		pad;				/* payload: int32 level[n_elem], nbr0[n_elem*2m], tid_count[n_elem]; int64 tids[n_elem*10];
 									 * int32 up_slot[n_elem], up_nbr[n_upper*max_level*m] */
-}			vsr_sc_hnsw;
+}			vsr_sc_hnsw_req;
 
 typedef struct
 {
 	uint64_t	handle;
 	int32_t		lists;
 	int32_t		pad;				/* payload: float centers[lists*dim], int32 row_list[nrows] */
-}			vsr_sc_ivf;
+}			vsr_sc_ivf_req;
 
 /* ---- client side (pg_shim/vsr_client.c): plain C, no PostgreSQL dependency ---- */
 typedef struct vsr_sc_conn vsr_sc_conn;
@@ -134,12 +136,12 @@ int			vsr_sc_corpus_load(vsr_sc_conn * c, uint64_t key, uint64_t version, const 
 							   const int64_t *blk, const int32_t *doc, vsr_sc_corpus_info * out);
 int			vsr_sc_rbac_load(vsr_sc_conn * c, uint64_t handle, const int32_t *ur_user, const int32_t *ur_role, int64_t n_ur,
 							 const int32_t *pa_role, const int32_t *pa_doc, int64_t n_pa);
-int			vsr_sc_search(vsr_sc_conn * c, const vsr_sc_search * req, const float *queries, int32_t *counts, int64_t *rows,
+int			vsr_sc_search(vsr_sc_conn * c, const vsr_sc_search_req * req, const float *queries, int32_t *counts, int64_t *rows,
 						  int64_t *blk, float *dist);
-int			vsr_sc_hnsw_load(vsr_sc_conn * c, const vsr_sc_hnsw * req, int dim2m_unused, const int32_t *level,
+int			vsr_sc_hnsw_load(vsr_sc_conn * c, const vsr_sc_hnsw_req * req, int dim2m_unused, const int32_t *level,
 							 const int32_t *nbr0, const int32_t *tid_count, const int64_t *tids, const int32_t *up_slot,
 							 const int32_t *up_nbr);
-int			vsr_sc_ivf_load(vsr_sc_conn * c, const vsr_sc_ivf * req, int dim, int64_t nrows, const float *centers,
+int			vsr_sc_ivf_load(vsr_sc_conn * c, const vsr_sc_ivf_req * req, int dim, int64_t nrows, const float *centers,
 							const int32_t *row_list);
 int			vsr_sc_corpus_drop(vsr_sc_conn * c, uint64_t key);
 int			vsr_sc_shutdown(vsr_sc_conn * c);

@@ -188,6 +188,8 @@ struct RerankParams {
     const uint32_t*    qcnt;           // [n_slots] appended keys (may exceed capq: overflow)
     uint32_t           capq;
     float              err_g;          // relative error bound of the screening dot product: |dot_s - dot| <= err_g |x| |q|
+    uint32_t           err_tight;      // 1: the flag test uses the bound itself (K2g's coarse planes: g ~ 2^-8, where the roomy
+                                       // multiples that cost nothing at g ~ 1e-5 would flag every query)
     const uint32_t*    qbad;           // [n_slots] != 0: the query's screening input was invalid (int8 path): flag it
     uint32_t           exact_screen;   // int8 planes: screening values are the exact distances, no re-rank, kp = k
     int                seeded;         // thresholds were seeded from a sample: also check completeness

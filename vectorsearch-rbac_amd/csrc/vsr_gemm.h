@@ -310,14 +310,43 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
             // ---- three stages ahead: stage g + 3 (of the next tile from K-step nks - 3 on) ----
             const uint32_t ks3 = ks + 3 < nks ? ks + 3 : ks + 3 - nks;
             if (ks + 3 == nks) rows_of(it + 1, a_nxt);       // (committed at K-step 4 <= nks - 4, a barrier ago at least)
-            if (ks + 3 < nks) issue(a_cur, ks3, (g + 3) & 3u);
-            else issue(a_nxt, ks3, (g + 3) & 3u);             // past the last tile: row 0, never used
+            const bool nxt = ks + 3 >= nks;                   // past the last tile: row 0, never used
+#if GM_SCHED < 2
+            if (!nxt) issue(a_cur, ks3, (g + 3) & 3u);
+            else issue(a_nxt, ks3, (g + 3) & 3u);
+#endif
             const uint4* sa = stage + (size_t) (g & 3u) * GM_STAGE_U4 + (size_t) (wm * 128) * GM_KC + frag_off;
             const uint4* sb = stage + (size_t) (g & 3u) * GM_STAGE_U4 + (size_t) (GM_BM + wn * 64) * GM_KC + frag_off;
             bf16x8 bfr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8, sb[j * 64]);
-#if GM_READS_UPFRONT
+#if GM_SCHED >= 2
+            // The four LDS-DMA pieces of stage g + 3 go out one by one BETWEEN the MFMA groups: a piece costs the issuing wave
+            // ~100 cycles, and issued in a burst right after the barrier both waves of a SIMD pay that at the same time, with
+            // the matrix pipe idle.  All twelve fragment reads first (an LDS-DMA write may not overtake an LDS read).
+            {
+                bf16x8 afr[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) afr[i] = __builtin_bit_cast(bf16x8, sa[i * 64]);
+                lds_u4* dst = (lds_u4*) (stage + (size_t) ((g + 3) & 3u) * GM_STAGE_U4);
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+                    for (int i = 2 * qd; i < 2 * qd + 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[j], acc[i][j], 0, 0, 0);
+                    const int pc = qd >> 1;
+                    if ((qd & 1) == 0) {
+                        const uint4* src = (nxt ? a_nxt[pc] : a_cur[pc]) + (size_t) ks3 * COARSE_SLAB_U4;
+                        __builtin_amdgcn_global_load_lds(as_global(src), dst + (wave * 2 + pc) * 64, 16, 0, 0);
+                    } else
+                        __builtin_amdgcn_global_load_lds(as_global(b_src[pc] + (size_t) ks3 * COARSE_SLAB_U4),
+                                                         dst + GM_BM * GM_KC + (wave * 2 + pc) * 64, 16, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#elif GM_READS_UPFRONT
             // all twelve fragment reads of the K-step are issued before its first MFMA: the LDS latency is paid once per
             // K-step, the later fragments arrive under the earlier blocks' MFMAs (counted lgkmcnt waits by the compiler)
             bf16x8 afr[8];
@@ -334,7 +363,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void gemm_screen_kernel(const ScanPa
 #if GM_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
-#if GM_SCHED
+#if GM_SCHED == 1
             // emitted order: the four B fragments and two A fragments, then per row block its four MFMAs and the read of
             // the A fragment two blocks ahead (the compiler's own order waits for LDS four times per K-step)
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);

@@ -1026,7 +1026,14 @@ __device__ __forceinline__ void rerank_body(const RerankParams& p, uint32_t slot
                 const float g = p.err_g;                                   // relative error of the screening dot product
                 const float nxm = *p.norm2_max;
                 float err;
-                if (p.metric == M_L2) err = 2.0f * g * (nxm + qn) + g * fabsf(a_last);
+                if (p.err_tight) {
+                    // |dot_s - dot| <= g |x||q|:  L2 value = |x|^2 + |q|^2 - 2 dot -> 2 g |x||q| <= g (|x|^2 + |q|^2);
+                    // IP -> g |x||q|;  cosine = 1 - dot / (|x||q|) -> g.  Plus the fp32 rounding of forming the value itself
+                    // (a few ulp of its largest term) and of the folded-threshold accumulator start (vsr_gemm.h)
+                    if (p.metric == M_L2) err = g * (nxm + qn) * 1.0001f + 4e-6f * (nxm + qn);
+                    else if (p.metric == M_IP) err = g * sqrtf(nxm * qn) * 1.0001f + 4e-6f * sqrtf(nxm * qn);
+                    else err = g * 1.0001f + 4e-6f;
+                } else if (p.metric == M_L2) err = 2.0f * g * (nxm + qn) + g * fabsf(a_last);
                 else if (p.metric == M_IP) err = 2.0f * g * sqrtf(nxm * qn);
                 else err = 8.0f * g;
                 if (!(a_last - err > d_k)) flag = 1;                       // also catches NaN

@@ -1815,6 +1815,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
     rr.qcnt = qcnt;
     rr.capq = GQ_CAP;
     rr.err_g = plan.k2g ? coarse_err_g(c->dim) : plane_err_g(c->dim);
+    rr.err_tight = plan.k2g ? 1u : 0u;
     rr.qbad = plan.int8 ? reinterpret_cast<const uint32_t*>(ds + off_qb) : nullptr;
     rr.exact_screen = plan.int8 ? 1u : 0u;
     rr.seeded = 1;
