@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r2", "traffic.json"),
                     help="PMC-derived HBM bytes per launch (tools/pmc_traffic.py) for roofline.traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharding", default="auto", choices=["auto", "placement", "rows"],
+                    help="N > 1: 'placement' = whole role partitions on GPUs, a query touches ONE GPU, no exchange (SURVEY 8e-ii); "
+                         "'rows' = contiguous row ranges, every query on every GPU, all-gather + merge (SURVEY 8e-i); auto = placement")
     ap.add_argument("--wiki-rows", type=int, default=5_000_000, help="rows of the 768-d legs' corpus (0: skip the legs)")
     ap.add_argument("--wiki-steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=20251121)
@@ -156,6 +159,223 @@ def roofline_of(st, dim, kernel, n_sess, alone=None):
     return r
 
 
+def place_roles(parent, weights, n_bins):
+    """Roles -> GPUs for the placement mode: the role tree in PRE-ORDER (children in id order: the order the generator
+    consumed the roles in) cut into n_bins contiguous runs of nearly equal weight.  Neighbours in pre-order share their
+    ancestors, so the permission classes near the root are replicated on few GPUs (an LPT packing of single roles balances
+    as well but scatters siblings: 1.8 x the corpus resident at 8 GPUs against ~1.2 x), and a run's weight misses the
+    average by at most one role.  Returns ({role: gpu}, per-GPU weight)."""
+    kids = {}
+    for r, p in parent.items():
+        kids.setdefault(p, []).append(r)
+    order, stack = [], [0]
+    while stack:
+        node = stack.pop()
+        if node:
+            order.append(node)
+        stack.extend(sorted(kids.get(node, []), reverse=True))
+    order = [r for r in order if r in weights] + sorted(r for r in weights if r not in parent)
+    total = float(sum(weights[r] for r in order)) or 1.0
+    where, load, acc, g = {}, [0.0] * n_bins, 0.0, 0
+    for r in order:
+        # the role goes to the next GPU once this one has reached its share (at least one role per GPU while roles last)
+        while g < n_bins - 1 and acc + 0.5 * weights[r] > (g + 1) * total / n_bins:
+            g += 1
+        where[r] = g
+        load[g] += weights[r]
+        acc += weights[r]
+    return where, load
+
+
+def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim_world, rehearsal):
+    """N > 1, role-partition placement (controller/dynamic_partition/search.py:54-58 searches exactly the
+    partition tables of a user's role combination): every ROLE lives on one GPU together with everything it can see (its
+    own permission class and its ancestors': the few classes near the root are replicated on the GPUs that host a
+    descendant), so a query is answered by ONE GPU from its resident rows and there is no data-path collective at all.
+    The step is the same 1000-query batch as at N = 1; each rank searches the queries of its roles.  Strong scaling:
+    total work fixed, value = 1000 x steps / the slowest rank's time."""
+    from vsrbac.datasets import sample_queries, sift_like_rows_at, tree_rbac
+    n, dim, k, nq = args.rows, args.dim, args.k, args.queries
+    parts = world if world > 1 else sim_world
+    legs = [m for m in args.legs.split(",") if m]
+    t0 = time.time()
+    rbac = tree_rbac(num_users=1000, num_roles=100, num_docs=n // 100, seed=args.seed)
+    role_of = {int(u): rs[0] for u, rs in rbac._user_roles_map.items()}        # tree RBAC: exactly one role per user
+    users_of = {}
+    for u, r in role_of.items():
+        users_of[r] = users_of.get(r, 0) + 1
+    # expected work a role attracts: its share of the queries x the rows each of them scans
+    weights = {r: users_of.get(r, 0) * len(d) for r, d in rbac.role_docs.items()}
+    where, load = place_roles(rbac.parent, weights, parts)
+    me = rank if world > 1 else int(os.environ.get("VSR_BENCH_SIM_RANK", str(int(np.argmax(load)))))
+    my_roles = sorted(r for r, g in where.items() if g == me)
+    my_docs = np.unique(np.concatenate([rbac.role_docs[r] for r in my_roles])).astype(np.int64)
+    rows_idx = (np.repeat((my_docs - 1) * 100, 100) + np.tile(np.arange(100), my_docs.size)).astype(np.int64)
+    x = sift_like_rows_at(rows_idx, dim, args.seed)
+    blk, doc = rows_idx + 1, (rows_idx // 100 + 1).astype(np.int32)
+    nb = max(1, min(args.batches, args.steps + args.warmup))
+    batches = []
+    for b in range(nb):
+        qrow, quser = sample_queries(nq, n, 1000, seed=args.seed + 1000 * b)
+        mine = np.flatnonzero(np.array([where[role_of[int(u)]] == me for u in quser]))
+        batches.append((qrow[mine], quser[mine]))
+    qvecs = [sift_like_rows_at(qr, dim, args.seed) if len(qr) else np.zeros((0, dim), np.float32) for qr, _ in batches]
+    t_gen = time.time() - t0
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    ctx = vsrbac.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    corpus = ctx.load_corpus(x, blk, doc)
+    corpus.load_rbac(rbac.user_roles, rbac.permissions)
+    MODES = {"prefilter": vsrbac.RANGES, "postfilter": vsrbac.BITMAP}
+    d_qs = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) if len(v) else torch.zeros((1, dim), device=dev) for v in qvecs]
+    filt = {m: [corpus.pack_filters([corpus.filter_for_user(int(u), MODES[m]) for u in qu]) for _, qu in batches] for m in legs}
+    t_load = time.time() - t0 - t_gen
+    n_sess = max(1, min(8, int(os.environ.get("VSR_BENCH_SESSIONS", "4"))))
+    sessions, mq = [ctx], max(1, max(len(qr) for qr, _ in batches))
+    for _ in range(1, n_sess):
+        cx = vsrbac.Context(local_rank)
+        cx.set_stream(torch.cuda.Stream(device=dev).cuda_stream)
+        sessions.append(cx)
+    if os.environ.get("VSR_BENCH_NO_U8_HINT") != "1":
+        for sess in sessions:
+            sess.set_query_hint(True)
+    outs = [{"blk": torch.empty((mq, k), dtype=torch.int64, device=dev), "doc": torch.empty((mq, k), dtype=torch.int32, device=dev),
+             "row": torch.empty((mq, k), dtype=torch.int64, device=dev), "dist": torch.empty((mq, k), dtype=torch.float32, device=dev),
+             "cnt": torch.empty((mq,), dtype=torch.int32, device=dev)} for _ in range(n_sess)]
+    state = {"i": 0, "leg": legs[0]}
+
+    def step():
+        i = state["i"]
+        state["i"] += 1
+        b, o = i % nb, outs[i % n_sess]
+        nqb = len(batches[b][0])
+        if nqb:
+            corpus.search_device(ptr(d_qs[b]), nqb, k, "l2", filt[state["leg"]][b], ptr(o["blk"]), ptr(o["doc"]), ptr(o["row"]),
+                                 ptr(o["dist"]), ptr(o["cnt"]), None, session=sessions[i % n_sess])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce(v, op):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=dev if not rehearsal else "cpu")
+        dist.all_reduce(tt, op=op)
+        return float(tt.item())
+
+    def flagged():
+        return int(reduce(float(sum(sess.screening_check(0)[0] for sess in sessions)), dist.ReduceOp.SUM if world > 1 else None))
+
+    def timed_leg(leg, steps, warmup):
+        state["leg"], state["i"] = leg, 0
+        for _ in range(warmup):
+            step()
+        barrier()
+        for sess in sessions:
+            sess.profiling(2)
+            sess.stats_reset()
+        before = flagged()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        t_enq = time.perf_counter() - t1
+        barrier()
+        mine = time.perf_counter() - t1
+        dt = reduce(mine, dist.ReduceOp.MAX if world > 1 else None)
+        st = None
+        for sess in sessions:
+            one = sess.stats()
+            sess.profiling(False)
+            if st is None:
+                st = one
+            else:
+                for key in ("scan_launches", "scan_ms", "scan_bytes", "scan_rows", "scan_pairs", "unique_rows"):
+                    st[key] = [a + b for a, b in zip(st[key], one[key])]
+        return {"dt": dt, "dt_this_rank": mine, "t_enq": t_enq, "stats": st, "flagged": flagged() - before,
+                "kernel": sessions[0].last_scan_kernel()}
+
+    results = {leg: timed_leg(leg, args.steps, args.warmup) for leg in legs}
+    if any(r["flagged"] for r in results.values()):
+        raise SystemExit(f"screening flagged queries in the timed region: { {m: r['flagged'] for m, r in results.items()} }")
+    head = results[legs[0]]
+    sustained = None
+    if args.sustained_s > 0:
+        s_steps = max(args.steps, int(args.sustained_s / max(head["dt"] / args.steps, 1e-6)))
+        s_steps = int(reduce(float(s_steps), dist.ReduceOp.MAX if world > 1 else None))      # the same count on every rank
+        srun = timed_leg(legs[0], s_steps, 1)
+        sustained = {"steps": s_steps, "seconds": round(srun["dt"], 3), "value": round(nq * s_steps / srun["dt"], 1),
+                     "ms_per_step": round(srun["dt"] / s_steps * 1e3, 4)}
+    # parity (default on): this rank's first queries of batch 0 against the oracle over the rows it holds -- by
+    # construction ALL rows those users may see; every rank checks its own, rank 0 reports the conjunction
+    from oracle.oracle import Oracle
+    orc = Oracle("pgflags")
+    m = min(8, len(batches[0][0]))
+    ok = 1.0
+    if m:
+        o = outs[0]
+        corpus.search_device(ptr(d_qs[0]), len(batches[0][0]), k, "l2", filt[legs[0]][0], ptr(o["blk"]), ptr(o["doc"]), ptr(o["row"]),
+                             ptr(o["dist"]), ptr(o["cnt"]), None)
+        torch.cuda.synchronize()
+        pos = {int(d): i * 100 for i, d in enumerate(my_docs)}                  # document -> first local row
+        ranges = [[(pos[int(d)], 100) for d in rbac.visible_docs(int(u)).astype(np.int64)] for u in batches[0][1][:m]]
+        rows_o, dist_o, _ = orc.search_ranges("l2", x, qvecs[0][:m], k, ranges, doc, blk)
+        ok = float((o["row"][:m].cpu().numpy() == rows_o).all() and (o["dist"][:m].cpu().numpy() == dist_o.astype(np.float32)).all())
+    ok_all = reduce(ok, dist.ReduceOp.MIN if world > 1 else None)
+    per_rank_q = [len(qr) for qr, _ in batches]
+    mean_q = reduce(float(np.mean(per_rank_q)), dist.ReduceOp.SUM if world > 1 else None)
+    if rank == 0:
+        roof = roofline_of(head["stats"], dim, head["kernel"], n_sess)
+        roof["note"] = "rank 0's main scan launches (its roles' rows); " + roof.get("note", "")
+        out = {
+            "metric": "QPS at recall@100, SIFT10M filtered-kNN (role RBAC), 1/2/4/8 MI355X",
+            "value": round(nq * args.steps / head["dt"], 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(head["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": ("int8 planes -> i32 (exact: bit-identical to the fp32 distances of vector.c)" if "PL=int8" in head["kernel"]
+                      else "bf16 planes -> f32 (screen), f32 exact re-rank" if "K2" in head["kernel"] else "f32"),
+            "data": "synthetic",
+            "config": {"workload": f"SIFT10M-like {n}x{dim} fp32 L2 k={k}, tree RBAC 1000 users/100 roles, role-partition "
+                                   f"{legs[0]}, exact filtered top-k, {nq} queries/step ({nb} distinct batches)",
+                       "rows": n, "dim": dim, "k": k, "queries_per_step": nq, "filter": legs[0],
+                       "sharding": f"role placement x{parts}: every role (and all it can see) on one GPU, a query touches one "
+                                   f"GPU, no exchange", "exchange": "none (no data-path collective)",
+                       "recall": 1.0 if ok_all else None, "batches_in_flight": n_sess},
+            "roofline": roof,
+            "placement": {"roles_on_this_rank": len(my_roles), "rows_on_this_rank": int(len(rows_idx)),
+                          "replicated_row_fraction_this_rank": round(len(rows_idx) / (n / parts) - 1.0, 3),
+                          "predicted_load_max_over_mean": round(max(load) / (sum(load) / parts), 3),
+                          "queries_per_step_this_rank": {"min": int(min(per_rank_q)), "mean": round(float(np.mean(per_rank_q)), 1),
+                                                         "max": int(max(per_rank_q))},
+                          "queries_per_step_all_ranks": round(mean_q, 1) if world > 1 else None},
+            "multi_rank_parity": {"queries_per_rank": m, "ids_and_distances_identical": bool(ok_all),
+                                  "checked": "every rank: its first queries of batch 0 against the oracle over the rows it holds"},
+            "setup_s": {"generate": round(t_gen, 1), "load": round(t_load, 1)},
+            "host_enqueue_ms_per_step": round(head["t_enq"] / args.steps * 1e3, 4),
+            "screening_flagged_queries": 0,
+        }
+        for leg in legs[1:]:
+            r = results[leg]
+            out[leg] = {"value": round(nq * args.steps / r["dt"], 1), "unit": "queries/s", "ms_per_step": round(r["dt"] / args.steps * 1e3, 4),
+                        "roofline": roofline_of(r["stats"], dim, r["kernel"], n_sess)}
+        if sustained:
+            out["sustained"] = sustained
+        if world == 1:
+            out["sim_world"] = {"parts": parts, "simulated_rank": me, "note": "ONE rank's share of the N-GPU job on one GPU (the "
+                                "rank with the largest predicted load unless VSR_BENCH_SIM_RANK says otherwise)"}
+        print(json.dumps(out), flush=True)
+    if not ok_all:
+        raise SystemExit("parity check failed on a rank: GPU results differ from the oracle")
+    corpus.free()
+    for cx in sessions[1:]:
+        cx.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -193,6 +413,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29617")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    sim_world_early = int(os.environ.get("VSR_BENCH_SIM_WORLD", "0")) if world == 1 else 0
+    if (world > 1 or sim_world_early > 1) and args.sharding in ("auto", "placement") and not nccl_one:
+        return placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim_world_early, rehearsal)
     n, dim, k, nq = args.rows, args.dim, args.k, args.queries
     legs = [m for m in args.legs.split(",") if m]
     lo, hi = shard_bounds(n, world, rank, align=100)  # keep documents (100 rows) whole per shard

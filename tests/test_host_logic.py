@@ -177,3 +177,38 @@ def test_bench_roofline_arithmetic():
     assert abs(r["achieved"] - 1.32e9 / 0.4e-3 / 1e9) < 1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
     assert r["fp32_equivalent"]["unique_bytes"] == 10_000_000 * 512
     assert r["frac"] <= 1.0 and r["mfma"]["frac"] < 0.1
+
+
+def test_role_placement_covers_every_query_exactly_once():
+    """bench.py's N > 1 placement (SURVEY 8e-ii): every role on one GPU with everything it can see; the ranks' query
+    subsets partition every batch; the predicted load is balanced; the rows a rank holds are exactly what its roles see."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from vsrbac.datasets import sample_queries, tree_rbac
+    n = 1_000_000
+    rbac = tree_rbac(num_users=1000, num_roles=100, num_docs=n // 100, seed=20251121)
+    role_of = {int(u): rs[0] for u, rs in rbac._user_roles_map.items()}
+    assert all(len(rs) == 1 for rs in rbac._user_roles_map.values())
+    users_of = {}
+    for u, r in role_of.items():
+        users_of[r] = users_of.get(r, 0) + 1
+    weights = {r: users_of.get(r, 0) * len(d) for r, d in rbac.role_docs.items()}
+    for parts in (2, 4, 8):
+        where, load = bench.place_roles(rbac.parent, weights, parts)
+        assert sorted(where) == sorted(rbac.role_docs) and set(where.values()) == set(range(parts))
+        assert max(load) / (sum(load) / parts) < 1.08                     # a run misses its share by at most one role
+        qrow, quser = sample_queries(1000, n, 1000, seed=7)
+        seen = np.zeros(1000, dtype=int)
+        total_rows = 0
+        for g in range(parts):
+            mine = np.array([where[role_of[int(u)]] == g for u in quser])
+            seen += mine
+            docs = np.unique(np.concatenate([rbac.role_docs[r] for r, gg in where.items() if gg == g]))
+            total_rows += docs.size * 100
+            for u in quser[mine][:20]:                                       # all a user may see is on the user's GPU
+                assert np.isin(rbac.visible_docs(int(u)), docs).all()
+        assert (seen == 1).all()
+        assert total_rows < 1.3 * n                                          # replication of the classes near the root stays modest
