@@ -218,6 +218,13 @@ int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim, int probe
 int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, int probes, int metric,
                    const vsr_filter* const* filters,
                    int64_t* out_block_ids, int32_t* out_doc_ids, int64_t* out_rows, float* out_dist, int32_t* out_counts);
+/* same with queries and results resident on the device (the serving form: nothing but the probed list ids, nq x probes x
+ * 4 bytes, crosses PCIe, because the planner that groups queries by list is host code).  Returns when every query is
+ * proven exact over its lists, like vsr_search_device_exact.  d_out_doc_ids / d_out_rows may be NULL. */
+int vsr_ivf_search_device(vsr_ivf* ivf, const float* d_queries, int nq, int dim, int k, int probes, int metric,
+                          const vsr_filter* const* filters,
+                          int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows, float* d_out_dist,
+                          int32_t* d_out_counts);
 
 /* ---- HNSW graph search (pgvector/src/hnswscan.c:15-45,179-316; hnswutils.c:813-976) -------------------------- */
 /* A graph as pgvector's in-memory build leaves it (hnswbuild.c:357-470): n_elem elements, each with a top level, up to 10

@@ -215,6 +215,19 @@ class IvfIndex:
         self.assign = np.zeros(n, dtype=np.int32)
         oracle.lib.orc_ivf_assign(METRICS[metric], dim, self.rows, n, self.centers, self.lists, self.assign)
 
+    @classmethod
+    def from_centers(cls, oracle, metric, rows, centers):
+        """An index over given centres (no k-means): the assignment pass of ivfbuild.c:141-227 only."""
+        self = cls.__new__(cls)
+        self.orc, self.metric = oracle, metric
+        self.rows = np.ascontiguousarray(rows, dtype=np.float32)
+        self.centers = np.ascontiguousarray(centers, dtype=np.float32)
+        n, dim = self.rows.shape
+        self.lists = len(self.centers)
+        self.assign = np.zeros(n, dtype=np.int32)
+        oracle.lib.orc_ivf_assign(METRICS[metric], dim, self.rows, n, self.centers, self.lists, self.assign)
+        return self
+
     def probe(self, q, probes):
         q = np.ascontiguousarray(q, dtype=np.float32)
         out = np.zeros(min(probes, self.lists), dtype=np.int32)

@@ -94,6 +94,58 @@ def test_ivf_build_assignment_on_the_gpu(ctx, oracle, sift60k):
     corpus.free()
 
 
+def test_ivf_device_search_and_more_than_8192_lists(ctx, oracle):
+    """vsr_ivf_search_device (queries and results resident; only the probed list ids cross PCIe) returns what the host
+    form returns, and the probe kernel takes the reloption's upper range (lists up to 32768, ivfflat.h:42-44: 9000 lists
+    here, beyond the 8192 the 64-bit LDS keys of round 2 allowed)."""
+    import torch
+    import vsrbac
+    rng = np.random.default_rng(77)
+    n, dim, lists = 20_000, 16, 9000
+    x = rng.integers(0, 64, (n, dim)).astype(np.float32)
+    doc = (np.arange(n) // 10 + 1).astype(np.int32)
+    blk = (np.arange(n) + 1).astype(np.int64)
+    centers = x[np.sort(rng.choice(n, lists, replace=False))] + 0.5
+    oivf = OracleIvf.from_centers(oracle, "l2", x, centers)
+    corpus = ctx.load_corpus(x, blk, doc)
+    ndocs = int(doc.max())
+    perms = [(1, int(d)) for d in rng.choice(np.arange(1, ndocs + 1), ndocs // 2, replace=False)]
+    ur = [(1, 1)]
+    corpus.load_rbac(ur, perms)
+    np.testing.assert_array_equal(corpus.ivf_assign(centers, "l2"), oivf.assign)
+    gpu = corpus.load_ivf(centers, oivf.assign)
+    nq, k, probes = 12, 10, 40
+    q = x[rng.integers(0, n, nq)] + rng.integers(-1, 2, (nq, dim)).astype(np.float32)
+    got_lists = gpu.probe(q, probes)
+    for i in range(nq):
+        assert got_lists[i].tolist() == oivf.probe(q[i], probes).tolist(), i
+    mask = oracle.user_row_mask(1, ur, perms, doc)
+    filt = [corpus.filter_for_user(1, vsrbac.RANGES)] * nq
+    host = gpu.search(q, k, probes, "l2", filt)
+    dq = torch.from_numpy(q).cuda()
+    d_blk = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
+    d_row = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
+    d_doc = torch.full((nq, k), -7, dtype=torch.int32, device="cuda")
+    d_dist = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    d_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gpu.search_device(dq.data_ptr(), nq, k, probes, "l2", filt, d_blk.data_ptr(), d_doc.data_ptr(), d_row.data_ptr(),
+                      d_dist.data_ptr(), d_cnt.data_ptr())
+    np.testing.assert_array_equal(d_cnt.cpu().numpy(), host.counts)
+    np.testing.assert_array_equal(d_row.cpu().numpy(), host.rows)
+    np.testing.assert_array_equal(d_blk.cpu().numpy(), host.block_ids)
+    np.testing.assert_array_equal(d_doc.cpu().numpy(), host.doc_ids)
+    np.testing.assert_array_equal(d_dist.cpu().numpy(), host.dist)
+    for i in range(nq):
+        idx, dist = oivf.search(q[i], k, probes, doc, blk, mask)
+        m = host.counts[i]
+        assert m == idx.size
+        np.testing.assert_array_equal(host.rows[i, :m], idx)
+        np.testing.assert_array_equal(host.dist[i, :m], dist.astype(np.float32))
+    gpu.free()
+    corpus.free()
+
+
 def test_ivf_cosine_opclass_on_unit_rows(ctx, oracle):
     """vector_cosine_ops: spherical k-means centres, probe by negative inner product, rows are unit vectors."""
     rng = np.random.default_rng(71)

@@ -47,7 +47,7 @@ namespace vsr {
 #define GM_SETPRIO 0
 #endif
 #ifndef GM_SCHED
-#define GM_SCHED 0
+#define GM_SCHED 2
 #endif
 constexpr int GM_THREADS = 512;
 constexpr int GM_BM = 256;                 // rows per workgroup tile

@@ -1207,8 +1207,10 @@ hipError_t launch_view_bitmap(const uint32_t* rank, uint32_t n_rows, const uint2
 __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, uint32_t q_stride, const float* centers, int dim,
                                                         int lists, int probes, int metric, int32_t* out)
 {
+    // one 32-bit monotone image of the distance per list (the list id is the slot): 32768 lists, the reloption's maximum
+    // (ivfflat.h:42-44), take 128 KiB of the CU's 160 KiB
     extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);     // [lists]
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);     // [lists]; 0xFFFFFFFF = taken (above the canonical NaN's image)
     __shared__ uint64_t s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* q = queries + (size_t) blockIdx.x * q_stride;         // (corpus rows as queries: the index build's assignment)
@@ -1224,12 +1226,16 @@ __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, ui
             for (int j = 0; j < dim; ++j) sum = __fadd_rn(sum, __fmul_rn(x[j], q[j]));
             sum = -sum;
         }
-        keys[c] = make_key(sum, (uint32_t) c);
+        keys[c] = mono_bits(sum);
     }
     __syncthreads();
     for (int pr = 0; pr < probes; ++pr) {
         uint64_t best = KEY_EMPTY;
-        for (int c = tid; c < lists; c += 256) best = keys[c] < best ? keys[c] : best;
+        for (int c = tid; c < lists; c += 256) {
+            const uint32_t kc = keys[c];
+            const uint64_t cand = kc == 0xFFFFFFFFu ? KEY_EMPTY : (((uint64_t) kc << 32) | (uint32_t) c);
+            best = cand < best ? cand : best;
+        }
         for (int m = 32; m >= 1; m >>= 1) {
             const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) best, m), hi = (uint32_t) __shfl_xor((int) (uint32_t) (best >> 32), m);
             const uint64_t o = ((uint64_t) hi << 32) | lo;
@@ -1241,7 +1247,7 @@ __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, ui
         for (int w = 1; w < 4; ++w) b = s_best[w] < b ? s_best[w] : b;
         if (tid == 0) {
             out[(size_t) blockIdx.x * probes + pr] = b == KEY_EMPTY ? -1 : (int32_t) (uint32_t) b;
-            if (b != KEY_EMPTY) keys[(uint32_t) b] = KEY_EMPTY;
+            if (b != KEY_EMPTY) keys[(uint32_t) b] = 0xFFFFFFFFu;
         }
         __syncthreads();
     }
@@ -1251,8 +1257,13 @@ hipError_t launch_ivf_probe(const float* queries, uint32_t q_stride, uint32_t nq
                             int metric, int32_t* out, hipStream_t s)
 {
     if (nq == 0) return hipSuccess;
-    const size_t lds = (size_t) lists * sizeof(uint64_t);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const size_t lds = (size_t) lists * sizeof(uint32_t);
+    if (lds > 128 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int) lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(ivf_probe_kernel, dim3(nq), dim3(256), lds, s, queries, q_stride, centers, dim, lists, probes, metric, out);
     return hipGetLastError();
 }

@@ -2746,34 +2746,25 @@ static int ivf_part(vsr_ivf* ivf, const vsr_filter* bf, int list, vsr_filter** o
     return VSR_OK;
 }
 
-extern "C" int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, int probes, int metric,
-                              const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
-                              float* out_dist, int32_t* out_cnt)
+// GetScanLists + the per-query filters of GetScanItems: the probe launch on device-resident queries, the probed list
+// ids back to the host (nq x probes x 4 bytes: the planner that groups queries by list is host code), one parts-only
+// filter of the view per query.
+static int ivf_plan(vsr_ivf* ivf, const float* d_queries, int nq, int dim, int probes, int metric,
+                    const vsr_filter* const* filters, std::vector<std::unique_ptr<vsr_filter>>& owned,
+                    std::vector<const vsr_filter*>& fl)
 {
-    if (!ivf) return fail(VSR_ERR_INVALID, "vsr_ivf_search: index is NULL");
-    vsr_corpus* main = ivf->main;
-    int rc = check_search_args(main, queries, nq, dim, k, metric, filters, "vsr_ivf_search");
-    if (rc) return rc;
-    if (metric == VSR_METRIC_L1) return fail(VSR_ERR_UNSUPPORTED, "vsr_ivf_search: ivfflat has no L1 operator class");
-    if (probes < 1) return fail(VSR_ERR_INVALID, "vsr_ivf_search: probes must be >= 1 (got %d)", probes);   /* ivfflat.c:41-45 */
-    if (nq == 0) return VSR_OK;
-    if (!out_blk || !out_dist || !out_cnt) return fail(VSR_ERR_INVALID, "vsr_ivf_search: output is NULL");
-    probes = std::min(probes, ivf->lists);
-    vsr_ctx* ctx = main->ctx;
-    HIPCHK(hipSetDevice(ctx->device));
-    // GetScanLists: the probes nearest lists of every query (cosine opclass: the caller passes normalised queries and the
-    // index distance is the negative inner product, vector.sql:323-327)
-    if ((rc = ivf->d_q.reserve((size_t) nq * dim * sizeof(float)))) return rc;
+    vsr_ctx* ctx = ivf->main->ctx;
+    int rc;
     if ((rc = ivf->d_probe.reserve((size_t) nq * probes * sizeof(int32_t)))) return rc;
-    HIPCHK(hipMemcpyAsync(ivf->d_q.p, queries, (size_t) nq * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(launch_ivf_probe(ivf->d_q.as<float>(), (uint32_t) dim, (uint32_t) nq, ivf->d_centers, dim, ivf->lists, probes,
+    // cosine opclass: the caller passes normalised queries and the index distance is the negative inner product
+    // (vector.sql:323-327)
+    HIPCHK(launch_ivf_probe(d_queries, (uint32_t) dim, (uint32_t) nq, ivf->d_centers, dim, ivf->lists, probes,
                             metric == VSR_METRIC_L2 ? M_L2 : M_IP, ivf->d_probe.as<int32_t>(), ctx->stream));
     std::vector<int32_t> probe((size_t) nq * probes);
     HIPCHK(hipMemcpyAsync(probe.data(), ivf->d_probe.p, probe.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    // GetScanItems: every query scans the rows of its lists (and only the permitted ones)
-    std::vector<std::unique_ptr<vsr_filter>> owned((size_t) nq);
-    std::vector<const vsr_filter*> fl((size_t) nq, nullptr);
+    owned.resize((size_t) nq);
+    fl.assign((size_t) nq, nullptr);
     for (int q = 0; q < nq; ++q) {
         std::unique_ptr<vsr_filter> f(new vsr_filter());
         f->corpus = ivf->view;
@@ -2792,7 +2783,53 @@ extern "C" int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int di
         fl[(size_t) q] = f.get();
         owned[(size_t) q] = std::move(f);
     }
+    return VSR_OK;
+}
+
+static int ivf_check(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, int& probes, int metric,
+                     const vsr_filter* const* filters, const void* o1, const void* o2, const void* o3, const char* who)
+{
+    if (!ivf) return fail(VSR_ERR_INVALID, "%s: index is NULL", who);
+    int rc = check_search_args(ivf->main, queries, nq, dim, k, metric, filters, who);
+    if (rc) return rc;
+    if (metric == VSR_METRIC_L1) return fail(VSR_ERR_UNSUPPORTED, "%s: ivfflat has no L1 operator class", who);
+    if (probes < 1) return fail(VSR_ERR_INVALID, "%s: probes must be >= 1 (got %d)", who, probes);   /* ivfflat.c:41-45 */
+    if (nq > 0 && (!o1 || !o2 || !o3)) return fail(VSR_ERR_INVALID, "%s: output is NULL", who);
+    probes = std::min(probes, ivf->lists);
+    return VSR_OK;
+}
+
+extern "C" int vsr_ivf_search(vsr_ivf* ivf, const float* queries, int nq, int dim, int k, int probes, int metric,
+                              const vsr_filter* const* filters, int64_t* out_blk, int32_t* out_doc, int64_t* out_row,
+                              float* out_dist, int32_t* out_cnt)
+{
+    int rc = ivf_check(ivf, queries, nq, dim, k, probes, metric, filters, out_blk, out_dist, out_cnt, "vsr_ivf_search");
+    if (rc || nq == 0) return rc;
+    vsr_ctx* ctx = ivf->main->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    if ((rc = ivf->d_q.reserve((size_t) nq * dim * sizeof(float)))) return rc;
+    HIPCHK(hipMemcpyAsync(ivf->d_q.p, queries, (size_t) nq * dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<std::unique_ptr<vsr_filter>> owned;
+    std::vector<const vsr_filter*> fl;
+    if ((rc = ivf_plan(ivf, ivf->d_q.as<float>(), nq, dim, probes, metric, filters, owned, fl))) return rc;
     return host_search(ivf->view, queries, nq, dim, k, metric, fl.data(), out_blk, out_doc, out_row, out_dist, out_cnt);
+}
+
+// The same with queries and results resident on the device.  Returns when every query is proven exact over its lists
+// (vsr_search_device_exact's contract); only the probed list ids cross PCIe.
+extern "C" int vsr_ivf_search_device(vsr_ivf* ivf, const float* d_queries, int nq, int dim, int k, int probes, int metric,
+                                     const vsr_filter* const* filters, int64_t* d_blk, int32_t* d_doc, int64_t* d_row,
+                                     float* d_dist, int32_t* d_cnt)
+{
+    int rc = ivf_check(ivf, d_queries, nq, dim, k, probes, metric, filters, d_blk, d_dist, d_cnt, "vsr_ivf_search_device");
+    if (rc || nq == 0) return rc;
+    vsr_ctx* ctx = ivf->main->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<std::unique_ptr<vsr_filter>> owned;
+    std::vector<const vsr_filter*> fl;
+    if ((rc = ivf_plan(ivf, d_queries, nq, dim, probes, metric, filters, owned, fl))) return rc;
+    return vsr_search_device_exact(nullptr, ivf->view, d_queries, nq, dim, k, metric, fl.data(), d_blk, d_doc, d_row, d_dist,
+                                   d_cnt, nullptr, nullptr);
 }
 
 extern "C" int vsr_ivf_probe(vsr_ivf* ivf, const float* queries, int nq, int dim, int probes, int metric, int32_t* out_lists)

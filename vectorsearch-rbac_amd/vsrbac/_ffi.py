@@ -63,6 +63,7 @@ SYMBOLS = {
     "vsr_ivf_kmeans": (_i, [_vp, _i, _i, _vp, _i64, _i, C.c_uint64, _vp, C.POINTER(_i)]),
     "vsr_ivf_probe": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vsr_ivf_search": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vsr_ivf_search_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_hnsw_load": (_i, [_vp, _i, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "vsr_hnsw_free": (_i, [_vp]),
     "vsr_hnsw_search": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

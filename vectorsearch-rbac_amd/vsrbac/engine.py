@@ -387,6 +387,13 @@ class IvfIndex:
         except Exception:
             pass
 
+    def search_device(self, d_queries, nq, k, probes, metric, filters, d_block, d_doc, d_rows, d_dist, d_counts):
+        """Device pointers (ints); returns when every query is proven exact over its lists (vsr_ivf_search_device)."""
+        farr, keep = self.corpus._filter_array(filters, nq)
+        check(self._lib.vsr_ivf_search_device(self._h, d_queries, nq, self.corpus.dim, int(k), int(probes), _metric(metric),
+                                              farr, d_block, d_doc, d_rows, d_dist, d_counts))
+        del keep
+
     def probe(self, queries, probes, metric="l2"):
         q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries, dtype=np.float32)))
         p = min(int(probes), self.lists)
