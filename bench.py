@@ -72,6 +72,8 @@ def parse():
                          "'rows' = contiguous row ranges, every query on every GPU, all-gather + merge (SURVEY 8e-i); auto = placement")
     ap.add_argument("--wiki-rows", type=int, default=5_000_000, help="rows of the 768-d legs' corpus (0: skip the legs)")
     ap.add_argument("--wiki-steps", type=int, default=5)
+    ap.add_argument("--index-rows", type=int, default=120_000, help="rows of the role partition the HNSW legs (CPU port and K4) index")
+    ap.add_argument("--ivf-rows", type=int, default=1_000_000, help="rows of the IVFFlat leg's corpus (0: skip the leg)")
     ap.add_argument("--seed", type=int, default=20251121)
     return ap.parse_args()
 
@@ -157,6 +159,199 @@ def roofline_of(st, dim, kernel, n_sess, alone=None):
         r["alone"] = {"launch_ms": round(a_ms, 4), "achieved": round(a_ach, 2), "frac": round(a_ach / a_peak, 4),
                       "launches": int(alone["scan_launches"][cls])}
     return r
+
+
+def start_cpu_hnsw_build(orc, x, rows_idx, seed):
+    """pgvector's HNSW build restated (oracle/vsr_index_oracle.c, serial like a backend's in-memory build) on a host thread
+    while the GPU legs run: the C call releases the GIL, so the build costs the bench no wall time."""
+    import threading
+    box = {}
+
+    def run():
+        from oracle.oracle import HnswIndex
+        t = time.perf_counter()
+        try:
+            box["sub"] = np.ascontiguousarray(x[rows_idx])
+            box["index"] = HnswIndex(orc, "l2", box["sub"], m=16, ef_construction=64, seed=seed)
+        except Exception as exc:                                     # reported, never required
+            box["error"] = repr(exc)
+        box["build_s"] = time.perf_counter() - t
+
+    box["thread"] = threading.Thread(target=run, daemon=True)
+    box["thread"].start()
+    return box
+
+
+def host_threads():
+    try:
+        return max(1, min(64, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(64, os.cpu_count() or 1))
+
+
+def hnsw_legs(args, torch, ctx, orc, box, qvec, k, dev):
+    """cpu_baseline.hnsw and the `hnsw` GPU leg on the SAME graph: pgvector's HNSW with the index parameters of the
+    reference's role-partition experiment (m = 16, ef_construction = 64; test_partition_prefilter_by_role.py:42-46) over
+    one role partition.  ef_search is swept upwards until recall@k against the exact scan of the partition reaches 0.95."""
+    import concurrent.futures
+    box["thread"].join()
+    if "error" in box:
+        return {"error": box["error"]}, {"error": box["error"]}
+    hidx, sub = box["index"], box["sub"]
+    dim = sub.shape[1]
+    hq = qvec[:100]
+    exact = [set(orc.filtered_topk("l2", sub, hq[i], k)[0].tolist()) for i in range(len(hq))]
+    recall_of = lambda got: float(np.mean([len(set(np.asarray(g).tolist()) & e) / max(1, len(e)) for g, e in zip(got, exact)]))
+    sweep, cpu_rows = [], {}
+    for ef in (40, 100, 200, 400, 800, 1600, 3200):
+        th = time.perf_counter()
+        got = [hidx.search(hq[i], ef)[0][:k] for i in range(len(hq))]
+        hs = time.perf_counter() - th
+        sweep.append({"ef_search": ef, "qps": round(len(hq) / hs, 1), "recall_at_k": round(recall_of(got), 4)})
+        cpu_rows[ef] = got[:10]
+        if sweep[-1]["recall_at_k"] >= 0.95:
+            break
+    ef_star = sweep[-1]["ef_search"]
+    gq = qvec[:1000]
+    threads = host_threads()
+    cuts = np.linspace(0, len(gq), threads + 1).astype(int)
+    ta = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(threads) as pool:
+        list(pool.map(lambda se: [hidx.search(gq[i], ef_star) for i in range(se[0], se[1])],
+                      [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]))
+    all_s = time.perf_counter() - ta
+    cpu = {"kind": "port", "cores": 1, "m": 16, "ef_construction": 64, "rows": int(len(sub)), "build_s": round(box["build_s"], 2),
+           "sweep": sweep, "recall_target": 0.95, "reached": bool(sweep[-1]["recall_at_k"] >= 0.95),
+           "all_cores": {"ef_search": ef_star, "value": round(len(gq) / all_s, 1), "unit": "queries/s", "threads": threads,
+                         "queries": int(len(gq))},
+           "sample": f"pgvector's HNSW restated (oracle/vsr_index_oracle.c; built on a host thread during the GPU legs), "
+                     f"{len(sub)} rows of one role partition, 100 queries per ef_search on one core, recall against the exact "
+                     f"scan of those rows; all_cores: 1000 queries fanned over host threads at the last ef_search"}
+    # the same graph on the GPU (K4): queries and results resident, one launch per 1000 queries
+    try:
+        c2 = ctx.load_corpus(sub)
+        gidx = c2.load_hnsw(hidx.export())
+        nq = len(gq)
+        d_q = torch.from_numpy(np.ascontiguousarray(gq)).to(dev)
+        o_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        o_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        o_row = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        o_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+        o_vis = torch.zeros((nq,), dtype=torch.int64, device=dev)
+        gsweep = []
+        for pt in sweep:
+            ef = pt["ef_search"]
+            call = lambda: gidx.search_device(ptr(d_q), nq, k, ef, "l2", None, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist),
+                                              ptr(o_cnt), ptr(o_vis))
+            call()
+            ctx.synchronize()
+            reps = 5
+            th = time.perf_counter()
+            for _ in range(reps):
+                call()
+            ctx.synchronize()
+            gs = (time.perf_counter() - th) / reps
+            rows_g, cnt_g = o_row.cpu().numpy(), o_cnt.cpu().numpy()
+            if (cnt_g < 0).any():                                  # the LDS visited set overflowed: the host form re-runs those
+                res, _ = gidx.search(gq, k, ef)
+                rows_g, cnt_g = res.rows, res.counts
+            same = all(np.array_equal(rows_g[i][:len(cpu_rows[ef][i])], cpu_rows[ef][i]) for i in range(10))
+            visited = int(o_vis.sum().item())
+            gbytes = visited * dim * 4
+            gsweep.append({"ef_search": ef, "qps": round(nq / gs, 1), "ms_per_call": round(gs * 1e3, 4),
+                           "recall_at_k": round(recall_of([rows_g[i][:int(cnt_g[i])] for i in range(len(hq))]), 4),
+                           "same_rows_as_cpu_port": bool(same), "visited_per_query": round(visited / nq, 1),
+                           "queries_rerun_with_global_visited_set": int((o_cnt.cpu().numpy() < 0).sum()),
+                           "roofline": {"bound": "hbm", "achieved": round(gbytes / gs / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(gbytes / gs / 1e9 / HBM_PEAK_GBS, 4), "bytes": int(gbytes)},
+                           "speedup_vs_cpu_one_core": round(nq / gs / pt["qps"], 1)})
+        gpu = {"kernel": "vsr::hnsw_search_kernel (K4)", "rows": int(len(sub)), "queries_per_call": int(nq), "sweep": gsweep,
+               "speedup_vs_cpu_all_cores_at_last_ef": round(gsweep[-1]["qps"] / cpu["all_cores"]["value"], 1),
+               "note": "the graph of cpu_baseline.hnsw searched by K4 through vsr_hnsw_search_device (queries and results "
+                       "resident, one launch per call).  roofline: the row bytes of every distance evaluation (visited "
+                       "elements x d x 4; SURVEY 8d's gather figure) over the launch time -- a graph walk is a chain of "
+                       "dependent gathers, latency- not bandwidth-bound, so the fraction is small by nature"}
+        gidx.free()
+        c2.free()
+    except Exception as exc:
+        gpu = {"error": repr(exc)}
+    return cpu, gpu
+
+
+def ivf_leg(args, torch, vsrbac, ctx, orc, x, blk, doc, qvec, k, dev):
+    """The `ivf` leg: CREATE INDEX ... USING ivfflat on the GPU (k-means on the sample, every row into its list), then
+    probes in {1, 4, 10, 32} through vsr_ivf_search_device; beside it pgvector's scan of the same lists on one core."""
+    n3 = min(int(args.ivf_rows), len(x))
+    lists = max(10, n3 // 1000)                                        # pgvector's guidance: rows / 1000 up to 1M rows
+    x3 = x[:n3]
+    dim = x3.shape[1]
+    c3 = ctx.load_corpus(x3, blk[:n3], doc[:n3])
+    tb = time.perf_counter()
+    want = max(lists * 50, 10000)
+    pick = np.sort(np.random.default_rng(args.seed).choice(n3, size=min(n3, want), replace=False))
+    centers, iters = ctx.ivf_kmeans(x3[pick], lists, "l2", args.seed)
+    t_km = time.perf_counter() - tb
+    row_list = c3.ivf_assign(centers, "l2")
+    t_as = time.perf_counter() - tb - t_km
+    gidx = c3.load_ivf(centers, row_list)
+    t_ld = time.perf_counter() - tb - t_km - t_as
+    nq = min(1000, len(qvec))
+    gq = np.ascontiguousarray(qvec[:nq])
+    d_q = torch.from_numpy(gq).to(dev)
+    o_blk = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    o_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    o_row = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    o_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    m = 50
+    exact = c3.search(gq[:m], k, "l2").rows
+    # the CPU side scans list-ordered rows (GetScanItems reads the probed lists' pages, nothing else)
+    order = np.argsort(row_list, kind="stable")
+    start = np.concatenate([[0], np.cumsum(np.bincount(row_list, minlength=lists))]).astype(np.int64)
+    x_lo = np.ascontiguousarray(x3[order])
+    sweep = []
+    for probes in (1, 4, 10, 32):
+        if probes > lists:
+            break
+        call = lambda: gidx.search_device(ptr(d_q), nq, k, probes, "l2", None, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist),
+                                          ptr(o_cnt))
+        call()
+        ctx.profiling(2)
+        ctx.stats_reset()
+        reps = 3
+        th = time.perf_counter()
+        for _ in range(reps):
+            call()
+        gs = (time.perf_counter() - th) / reps
+        st = ctx.stats()
+        ctx.profiling(False)
+        kern = ctx.last_scan_kernel()
+        rows_g, dist_g = o_row.cpu().numpy(), o_dist.cpu().numpy()
+        rec = float(np.mean([len(set(rows_g[i].tolist()) & set(exact[i].tolist())) / k for i in range(m)]))
+        pl = gidx.probe(gq[:m], probes, "l2")
+        tc = time.perf_counter()
+        rows_o, dist_o, _ = orc.search_ranges("l2", x_lo, gq[:m], k, [[(int(start[l]), int(start[l + 1] - start[l])) for l in pl[i]]
+                                                                      for i in range(m)])
+        cs = time.perf_counter() - tc
+        same = bool(all(np.array_equal(np.sort(order[rows_o[i][rows_o[i] >= 0]]), np.sort(rows_g[i][rows_g[i] >= 0])) for i in range(m))
+                    and np.array_equal(dist_o.astype(np.float32)[:, :k], dist_g[:m]))
+        roof = roofline_of(st, dim, kern, 1) if sum(st["scan_launches"]) else None
+        sweep.append({"probes": probes, "qps": round(nq / gs, 1), "ms_per_call": round(gs * 1e3, 3), "recall_at_k": round(rec, 4),
+                      "cpu_port_qps_one_core": round(m / cs, 1), "same_rows_and_distances_as_cpu_port": same,
+                      "speedup_vs_cpu_one_core": round(nq / gs / (m / cs), 1), "roofline": roof})
+    out = {"kernel": "vsr::ivf_probe_kernel (K3) + the list scan the planner picks", "rows": int(n3), "lists": int(lists),
+           "queries_per_call": int(nq),
+           "build": {"kmeans_s": round(t_km, 2), "kmeans_iterations": int(iters), "samples": int(len(pick)), "assign_s": round(t_as, 2),
+                     "load_s": round(t_ld, 2), "note": "vsr_ivf_kmeans + vsr_ivf_assign + vsr_ivf_load (ivfbuild.c / ivfkmeans.c on the GPU)"},
+           "sweep": sweep,
+           "note": "vsr_ivf_search_device: queries and results resident; the probed list ids (nq x probes x 4 bytes) go to the host "
+                   "planner, which groups queries by list so a list shared by many queries is streamed once.  roofline: the dominant "
+                   "scan launch class of the call (event-timed), rows counted once.  CPU port: pgvector's GetScanItems over the same "
+                   "lists (oracle, one core, 50 queries)"}
+    gidx.free()
+    c3.free()
+    return out
 
 
 def place_roles(parent, weights, n_bins):
@@ -430,6 +625,16 @@ def main():
     allrows = np.concatenate([qr for qr, _ in batches])
     allvec = sift_like_rows_at(allrows, dim, args.seed)   # query vectors = corpus rows (read_dataset_function.py:736-737)
     t_gen = time.time() - t0
+    hnsw_box = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and int(os.environ.get("VSR_BENCH_SIM_WORLD", "0")) <= 1:
+        from oracle.oracle import Oracle as _OracleEarly
+        vis0 = rbac.visible_docs(int(batches[0][1][0])).astype(np.int64)
+        part_rows = (((vis0 - 1) * 100)[:, None] + np.arange(100)[None, :]).reshape(-1)
+        part_rows = part_rows[part_rows < len(x)]
+        if len(part_rows) < args.index_rows:                       # a small role: top up with the rows that follow
+            extra = np.setdiff1d(np.arange(min(len(x), args.index_rows * 2)), part_rows)[:args.index_rows - len(part_rows)]
+            part_rows = np.sort(np.concatenate([part_rows, extra]))
+        hnsw_box = start_cpu_hnsw_build(_OracleEarly("pgflags"), x, part_rows[:args.index_rows], args.seed)
 
     # every batch runs on an explicit stream (the null stream would order itself against all blocking streams)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
@@ -935,7 +1140,7 @@ def main():
         # the same sample fanned over host threads, one query per thread at a time (the C call releases the GIL):
         # an all-cores figure beside the single-core one; never the headline
         import concurrent.futures
-        threads = max(1, min(16, os.cpu_count() or 1))
+        threads = host_threads()
         cuts = np.linspace(0, m, threads + 1).astype(int)
         ta = time.perf_counter()
         with concurrent.futures.ThreadPoolExecutor(threads) as pool:
@@ -950,55 +1155,18 @@ def main():
         }
         out["cpu_baseline"]["all_cores"] = {"value": round(m / cpu_all_s, 1), "unit": "queries/s", "threads": threads,
                                             "note": "same sample, queries fanned over host threads"}
-        # CPU baseline no. 2: pgvector's HNSW (restated in oracle/vsr_index_oracle.c) with the index parameters of the
-        # reference's role-partition experiment (m = 16, ef_construction = 64; test_partition_prefilter_by_role.py:42-46),
-        # one core, on a bounded sample: the first 30k rows of one role partition, 100 queries per ef_search
-        try:
-            from oracle.oracle import HnswIndex
-            rows_idx = np.concatenate([np.arange(s0, s0 + c0) for s0, c0 in ranges[0]])[:30000]
-            sub = np.ascontiguousarray(x[rows_idx])
-            tb = time.perf_counter()
-            hidx = HnswIndex(orc, "l2", sub, m=16, ef_construction=64, seed=args.seed)
-            build_s = time.perf_counter() - tb
-            hq = qvec[:100]
-            exact = [set(orc.filtered_topk("l2", sub, hq[i], k)[0].tolist()) for i in range(len(hq))]
-            sweep = []
-            for ef in (40, 200, 500):
-                th = time.perf_counter()
-                got = [hidx.search(hq[i], ef)[0][:k] for i in range(len(hq))]
-                hs = time.perf_counter() - th
-                rec = float(np.mean([len(set(g.tolist()) & e) / max(1, len(e)) for g, e in zip(got, exact)]))
-                sweep.append({"ef_search": ef, "qps": round(len(hq) / hs, 1), "recall_at_k": round(rec, 4)})
-            out["cpu_baseline"]["hnsw"] = {
-                "kind": "port", "cores": 1, "m": 16, "ef_construction": 64, "rows": int(len(sub)), "build_s": round(build_s, 2),
-                "sweep": sweep, "sample": "pgvector's HNSW restated (oracle/vsr_index_oracle.c), first 30k rows of one role "
-                                          "partition, 100 queries per ef_search, recall against the exact scan of those rows"}
-            # ... and the same graph searched by K4 on the GPU (vsr_hnsw_search: one wave per query), 1000 queries per call
+        # CPU baseline no. 2 and the index legs: pgvector's HNSW on a whole role partition (CPU port; the same graph on K4),
+        # and IVFFlat built and probed on the GPU beside the CPU port's scan of the same lists
+        if hnsw_box is not None:
             try:
-                c2 = ctx.load_corpus(sub)
-                gidx = c2.load_hnsw(hidx.export())
-                gq = qvec[:1000]
-                gsweep = []
-                for ef, cpu_pt in zip((40, 200, 500), sweep):
-                    gidx.search(gq[:64], k, ef)                       # warm-up
-                    th = time.perf_counter()
-                    gres, _ = gidx.search(gq, k, ef)
-                    gs = time.perf_counter() - th
-                    cpu_rows = [hidx.search(hq[i], ef)[0][:k] for i in range(10)]
-                    same = all(np.array_equal(gres.rows[i][:len(cpu_rows[i])], cpu_rows[i]) for i in range(10))
-                    rec = float(np.mean([len(set(gres.rows[i][:int(gres.counts[i])].tolist()) & exact[i]) / max(1, len(exact[i]))
-                                         for i in range(len(hq))]))
-                    gsweep.append({"ef_search": ef, "qps": round(len(gq) / gs, 1), "recall_at_k": round(rec, 4),
-                                   "same_rows_as_cpu_port": bool(same)})
-                out["hnsw_gpu"] = {"kernel": "vsr::hnsw_search_kernel (K4)", "rows": int(len(sub)), "queries_per_call": int(len(gq)),
-                                   "sweep": gsweep, "note": "the graph of cpu_baseline.hnsw searched on the GPU through the host "
-                                                            "API (queries and results cross PCIe inside the timed call)"}
-                gidx.free()
-                c2.free()
+                out["cpu_baseline"]["hnsw"], out["hnsw"] = hnsw_legs(args, torch, ctx, orc, hnsw_box, qvec, k, dev)
+            except Exception as exc:      # the baseline is reported, never required
+                out["cpu_baseline"]["hnsw"] = {"error": repr(exc)}
+        if args.ivf_rows > 0:
+            try:
+                out["ivf"] = ivf_leg(args, torch, vsrbac, ctx, orc, x, blk, doc, qvec, k, dev)
             except Exception as exc:
-                out["hnsw_gpu"] = {"error": repr(exc)}
-        except Exception as exc:      # the baseline is reported, never required
-            out["cpu_baseline"]["hnsw"] = {"error": repr(exc)}
+                out["ivf"] = {"error": repr(exc)}
         checks = {leg: spot_check(leg, orc, m) for leg in legs}
         out["parity_spot_check"] = checks[legs[0]]
         for leg in legs[1:]:

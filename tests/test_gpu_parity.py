@@ -720,16 +720,16 @@ def test_int8_planes_for_sift_like_queries(ctx, oracle):
     q = x[rng.integers(0, n, nq)].copy()
     q[:, :7] = rng.integers(0, 256, (nq, 7)).astype(np.float32)        # still integers 0..255, no longer corpus rows
     res = corpus.search(q, k, "l2")
-    assert "PL=int8" in ctx.last_scan_kernel(), ctx.last_scan_kernel()
+    assert "int8" in ctx.last_scan_kernel(), ctx.last_scan_kernel()
     for i in range(0, nq, 7):
         _expect_exact(oracle, res, i, "l2", x, q[i], k, doc, blk)
     q2 = q.copy()
     q2[5, 3] = 17.5                                                    # one non-integer element: bf16 planes for this call
     res = corpus.search(q2, k, "l2")
-    assert "PL=int8" not in ctx.last_scan_kernel()
+    assert "int8" not in ctx.last_scan_kernel()
     _expect_exact(oracle, res, 5, "l2", x, q2[5], k, doc, blk)
     res = corpus.search(q, k, "ip")                                    # int8 planes are an L2 path only
-    assert "PL=int8" not in ctx.last_scan_kernel()
+    assert "int8" not in ctx.last_scan_kernel()
     # device-resident queries: nothing is assumed without the hint
     dev = torch.device("cuda", 0)
     outs = (torch.empty((nq, k), dtype=torch.int64, device=dev), torch.empty((nq, k), dtype=torch.int32, device=dev),
@@ -739,11 +739,11 @@ def test_int8_planes_for_sift_like_queries(ctx, oracle):
     d_q = torch.from_numpy(q).to(dev)
     corpus.search_device(d_q.data_ptr(), nq, k, "l2", None, *ptrs)
     ctx.synchronize()
-    assert "PL=int8" not in ctx.last_scan_kernel()
+    assert "int8" not in ctx.last_scan_kernel()
     ctx.set_query_hint(True)
     corpus.search_device(d_q.data_ptr(), nq, k, "l2", None, *ptrs)
     _, flags = ctx.screening_check(nq)
-    assert "PL=int8" in ctx.last_scan_kernel() and not flags.any()
+    assert "int8" in ctx.last_scan_kernel() and not flags.any()
     got = SimpleNamespace(block_ids=outs[0].cpu().numpy(), doc_ids=outs[1].cpu().numpy(), rows=outs[2].cpu().numpy(),
                           dist=outs[3].cpu().numpy(), counts=outs[4].cpu().numpy())
     for i in range(0, nq, 9):
@@ -762,7 +762,7 @@ def test_int8_planes_for_sift_like_queries(ctx, oracle):
         _expect_exact(oracle, got, i, "l2", x, q2[i], k, doc, blk)
     corpus.search_device(d_q.data_ptr(), nq, k, "l2", None, *ptrs)     # the violation dropped the hint
     ctx.synchronize()
-    assert "PL=int8" not in ctx.last_scan_kernel()
+    assert "int8" not in ctx.last_scan_kernel()
     ctx.set_query_hint(False)
     corpus.free()
 

@@ -1,0 +1,364 @@
+// vsr_i8s.h — K2i: the int8 main launch as independent per-wave streams (SIFT-like corpora: d = 65 .. 128, u8-exact rows).
+//
+// K2w's int8 instantiation (vsr_mfmaw.h) stages a 64-row tile per WORKGROUP through registers: load -> ds_write -> barrier
+// -> fragment reads, one tile (8 KB) per workgroup in flight, four workgroups per CU = 32 KB per CU.  HBM needs about
+// 8 TB/s x 2 us = 16 MB in flight chip-wide (64 KB per CU) before it streams at full rate; the counters of round 2 showed
+// the waves waiting 59 % of their cycles and the launch at 4.8 TB/s of pass bytes.  A deeper register ring costs VGPRs the
+// kernel does not have (measured: spills).  K2i keeps the arithmetic and the candidate protocol and changes the data path:
+//
+//   * every WAVE is its own stream: it owns a ring of four 32-row stages in LDS (4 KB each), fills it with LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers, no ds_write), reads its A fragments from its own ring and multiplies
+//     them against ALL the pass's queries, whose B fragments (up to 64 queries x 128 bytes) sit in its registers.  Nothing is
+//     shared between the waves of a workgroup inside the loop, so there is NO barrier: a wave waits for its own loads with
+//     a counted s_waitcnt vmcnt and three stages (12 KB) per wave stay in flight: 8 waves per CU = 96 KB per CU;
+//   * the row mapping (list tile -> first row, row count, permission bits) rides in the same queue as 4-byte LDS-DMA loads,
+//     32 list tiles (16 stages) at a time and two such chunks ahead; |row|^2 of a stage's 32 rows is one more LDS-DMA load
+//     next to its four row pieces.  No load of the loop's common path returns into a register, so no wait drains the queue;
+//   * the candidate test is K2w's integer test: the chain of query column j starts at c0 = ceil((tau - |q|^2) / 2), a
+//     pair is a candidate when acc >= floor(|x|^2 / 2) (one v_cmp per pair).  Candidates (~1.5 per stage) are parked in
+//     LDS; when half the parking area is used the wave reserves room for all of them with one returning atomic per query
+//     column and stores the keys -- synchronously: that wait drains the stream, once per ~20 stages.
+//
+// Two things the compiler must not do to this loop (hipcc, ROCm 7.2; checked in the .s): (1) wait for the B fragments'
+// loads inside the loop -- they are first used in blocks it branches around, so an empty asm "uses" them before the loop;
+// (2) put s_waitcnt vmcnt(0) in front of an LDS read because LDS-DMA writes are pending: reads written as
+// __builtin_bit_cast(vector, ((const uint4*) p)[i]) are left alone, reads through float4 / int4 / scalar lvalues of a region
+// that is also stored to are not (observed, not explained).
+//
+// LDS image of a stage: 32 rows x 8 chunks of 16 bytes; chunk c of row r sits at position c ^ ((r >> 1) & 7), applied on the
+// SOURCE address of the DMA (the DMA writes lane i at base + 16 i): the sixteen lanes of an A-fragment read (rows 0..15 of
+// a block, one k-chunk) then cover sixteen different 16-byte bank groups.
+//
+// Same inputs and outputs as K2w's main launch (ScanParams: groups, tiles, bitmaps, thresholds, per-query candidate
+// buffers); the sample pass stays K2w's.  The launcher falls back to K2w when the shape does not fit (rw != 16, an
+// explicit sample stride, the rounds epilogue).
+#pragma once
+#include "vsr_device.h"
+#include "vsr_topk.h"
+#include "vsr_mfma.h"
+#include "vsr_gemm.h"
+
+namespace vsr {
+
+constexpr int KI_THREADS = 256;
+constexpr int KI_WAVES = 4;
+constexpr int KI_ROWS = 32;                // rows per stage: two list tiles of 16 rows
+constexpr int KI_SLOTS = 4;                // stage ring of a wave: one being multiplied, three in flight
+constexpr int KI_STAGE_U4 = KI_ROWS * 8;   // uint4 per stage (4 KB)
+constexpr int KI_CHUNK = 16;               // stages per mapping chunk (32 list tiles)
+constexpr int KI_PARK = 64;                // candidates a wave parks before it reserves room for them
+constexpr int KI_FLUSH_AT = 32;            // ... and the fill level that triggers the reservation
+constexpr int KI_NQ = 64;                  // query columns of a pass
+// per wave: [stage ring | |row|^2 ring | thresholds of the current stage | descriptor ring (3 chunks) | permission words ring
+// (2 chunks) | parked candidates {value, row, column} | per-column counts]; per workgroup: [column constants]
+constexpr size_t KI_WAVE_BYTES = (size_t) KI_SLOTS * KI_STAGE_U4 * 16 + KI_SLOTS * KI_ROWS * 4 + KI_ROWS * 4 + 3 * 2 * (2 * KI_CHUNK) * 4 +
+                                 2 * 4 * (2 * KI_CHUNK) * 4 + KI_PARK * 12 + 64 * 4;
+inline size_t i8s_lds_bytes() { return KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16; }
+static_assert(2 * (KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16) <= 160 * 1024, "two workgroups per CU");
+
+template <int NQG>
+__global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    uint32_t lo = 0, mapped_block = 0;
+    if (p.block_map) {
+        const uint2 m = p.block_map[blockIdx.x];
+        if (m.x == 0xFFFFFFFFu) return;                                        // padding workgroup of a short XCD lane
+        lo = m.x;
+        mapped_block = m.y;
+    } else {
+        uint32_t hi = p.n_groups;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (p.groups[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid;
+        }
+    }
+    const ScanGroup grp = p.groups[lo];
+    const uint32_t local_block = p.block_map ? mapped_block : blockIdx.x - grp.block_begin;
+    const auto g_tiles = as_global(grp.tiles);
+    const auto g_bitmap = as_global(grp.bitmap ? grp.bitmap : p.ones);          // no bitmap: one all-ones word
+    const bool has_bitmap = grp.bitmap != nullptr;
+    const auto g_norm2 = as_global(p.norm2);
+    const auto g_rank = as_global(p.rank);
+    const uint32_t q_count = grp.q_count;
+
+    unsigned char* wbase = smem + (size_t) wave * KI_WAVE_BYTES;
+    uint4*    ring = reinterpret_cast<uint4*>(wbase);                           // [4][32 rows][8 chunks]
+    float*    nring = reinterpret_cast<float*>(wbase + (size_t) KI_SLOTS * KI_STAGE_U4 * 16);   // [4][32] |row|^2 (DMA)
+    int32_t*  thr = reinterpret_cast<int32_t*>(nring + KI_SLOTS * KI_ROWS);     // [32] floor(|row|^2 / 2); no row: INT_MAX
+    constexpr uint32_t CT = 2 * KI_CHUNK;                                       // list tiles per mapping chunk
+    uint32_t* dring = reinterpret_cast<uint32_t*>(thr + KI_ROWS);               // [3][2][CT] descriptor words x | y of a chunk's list tiles
+    uint32_t* wring = dring + 3 * 2 * CT;                                       // [2][4][CT] permission words (w0 lo, hi, w1 lo, hi)
+    uint32_t* pk_v = wring + 2 * 4 * CT;                                        // parked candidates: key high word
+    uint32_t* pk_r = pk_v + KI_PARK;                                            //                    row
+    uint32_t* pk_c = pk_r + KI_PARK;                                            //                    query column
+    uint32_t* pk_n = pk_c + KI_PARK;                                            // [64] candidates per column
+    float4*   colc = reinterpret_cast<float4*>(smem + KI_WAVES * KI_WAVE_BYTES);   // [64] {c0 bits, |q|^2, slot bits, -}
+
+    // ---- query columns: the thresholds folded into what the integer accumulators start from (vsr_mfmaw.h, ITEST) ----
+    if (tid < KI_NQ) {
+        const bool qok = (uint32_t) tid < q_count;
+        const uint32_t slot = p.q_slots[grp.q_begin + (qok ? (uint32_t) tid : 0u)];
+        const uint64_t tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
+        const bool open = tau == KEY_EMPTY;
+        const float lim = open ? __builtin_inff() : mono_to_float((uint32_t) (tau >> 32));
+        const float qn = p.q_norm2[slot];
+        const int32_t c0 = !qok ? -0x40000000 : open ? 0x3FFFFFFF : (((int32_t) lim - (int32_t) qn) + 1) >> 1;
+        colc[tid] = make_float4(__int_as_float(c0), qn, __uint_as_float(qok ? slot : 0xFFFFFFFFu), 0.0f);
+    }
+    __syncthreads();
+
+    // MFMA lane roles (16x16x64 int8): A lane = (row li, 16-byte k-chunk kq); B / result lane = (k-chunk kq | row quad kq, query li)
+    const int li = lane & 15;
+    const int kq = lane >> 4;
+    const uint32_t ngt = (q_count + 15u) >> 4;                                  // 16-query groups in use (wave-uniform)
+    i32x4 b8[NQG][2];
+    int32_t c0j[NQG];
+#pragma unroll
+    for (int j = 0; j < NQG; ++j) {
+        const uint32_t qi = (uint32_t) (j * 16 + li);
+        const uint32_t slot = p.q_slots[grp.q_begin + (qi < q_count ? qi : 0u)];
+        const uint4* qsrc = p.q_scr + (size_t) slot * p.pstride4;
+        b8[j][0] = __builtin_bit_cast(i32x4, qsrc[kq]);
+        b8[j][1] = __builtin_bit_cast(i32x4, qsrc[4 + kq]);
+        c0j[j] = __float_as_int(colc[qi].x);
+    }
+    // the fragments are first used inside the loop, in blocks the compiler branches around: without a use here it would wait
+    // for "their" loads (vmcnt(0): the whole queue) at every one of those blocks of every stage
+#pragma unroll
+    for (int j = 0; j < NQG; ++j) asm volatile("" : "+v"(b8[j][0]), "+v"(b8[j][1]), "+v"(c0j[j]));
+
+    // ---- this wave's stages: stage i of the wave = list tiles t0 + 2 (wave + 4 i) + {0, 1} of the workgroup's range ----
+    const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
+    const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
+    const uint32_t n_st = (t1 - t0 + 1u) >> 1;
+    const uint32_t n_w = n_st > (uint32_t) wave ? (n_st - (uint32_t) wave + 3u) >> 2 : 0u;
+    if (n_w == 0) return;                                                       // (after the only workgroup barrier)
+    const uint32_t tile_last = grp.n_tiles - 1u;
+    const uint32_t last_row = p.n_rows - 1u;
+
+    // mapping chunk c -> LDS: lane L < CT holds list tile (stage KI_CHUNK c + (L >> 1), half L & 1)
+    auto chunk_tile = [&](uint32_t c) -> uint32_t { return t0 + 2u * ((uint32_t) wave + 4u * (c * KI_CHUNK + ((uint32_t) lane >> 1))) + ((uint32_t) lane & 1u); };
+    auto fetch_desc = [&](uint32_t c) {
+        if ((uint32_t) lane >= CT) return;
+        const uint32_t t = chunk_tile(c);
+        const gptr<uint32_t> src = (gptr<uint32_t>) (g_tiles + (t < tile_last ? t : tile_last));
+        uint32_t* dst = dring + (c % 3u) * (2 * CT);
+        __builtin_amdgcn_global_load_lds(src, (lds_u32*) dst, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 1, (lds_u32*) dst + CT, 4, 0, 0);
+    };
+    // (start row, rows) of a chunk's list tile as this wave sees it: tiles past the workgroup's range hold no rows
+    auto desc_of = [&](uint32_t c, uint32_t idx, uint32_t t) -> uint2 {
+        const uint32_t* d = dring + (c % 3u) * (2 * CT);
+        const bool ok = t < t1;
+        return make_uint2(ok ? d[idx] : 0u, ok ? d[CT + idx] : 0u);
+    };
+    auto fetch_words = [&](uint32_t c) {                                       // needs chunk c's descriptors in LDS
+        if (!has_bitmap || (uint32_t) lane >= CT) return;
+        const uint2 d = desc_of(c, (uint32_t) lane, chunk_tile(c));
+        const uint32_t r0 = d.x <= last_row ? d.x : last_row;
+        const gptr<uint32_t> src = (gptr<uint32_t>) (g_bitmap + (r0 >> 6));    // (bitmaps carry two pad words: the window never leaves them)
+        uint32_t* dst = wring + (c & 1u) * (4 * CT);
+        __builtin_amdgcn_global_load_lds(src, (lds_u32*) dst, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 1, (lds_u32*) dst + CT, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 2, (lds_u32*) dst + 2 * CT, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 3, (lds_u32*) dst + 3 * CT, 4, 0, 0);
+    };
+
+    // rows + |row|^2 of stage i into ring slot i & 3: four 1-KB pieces (8 rows x 128 bytes) and one 128-byte norm piece.  Always
+    // five operations, also past the wave's last stage (row 0, never used), so that the counted wait below is exact.
+    bool bad_row = false;
+    auto issue = [&](uint32_t i) {
+        const uint32_t c = i / KI_CHUNK, e = (i % KI_CHUNK) * 2u;
+        const uint32_t tb = t0 + 2u * ((uint32_t) wave + 4u * i);
+        const uint2 d0 = desc_of(c, e, tb), d1 = desc_of(c, e + 1u, tb + 1u);
+        const uint32_t slot_ = i & (KI_SLOTS - 1);
+        lds_u4* dst = (lds_u4*) (ring + (size_t) slot_ * KI_STAGE_U4);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const uint2 d = pc < 2 ? d0 : d1;
+            const uint32_t o = (uint32_t) ((pc & 1) * 8) + ((uint32_t) lane >> 3);
+            uint32_t row = d.x + (o < d.y ? o : 0u);
+            row = row <= last_row ? row : last_row;
+            const uint32_t ch = ((uint32_t) lane & 7u) ^ (((uint32_t) (pc * 4) + ((uint32_t) lane >> 4)) & 7u);
+            __builtin_amdgcn_global_load_lds(as_global(p.scr + (size_t) row * 8u + ch), dst + pc * 64, 16, 0, 0);
+        }
+        if (lane < KI_ROWS) {
+            const uint2 d = lane < 16 ? d0 : d1;
+            const uint32_t o = (uint32_t) lane & 15u;
+            uint32_t row = d.x + (o < d.y ? o : 0u);
+            row = row <= last_row ? row : last_row;
+            __builtin_amdgcn_global_load_lds((gptr<uint32_t>) (g_norm2 + row), (lds_u32*) (nring + slot_ * KI_ROWS), 4, 0, 0);
+        }
+    };
+
+    // Parked candidates -> their queries' buffers: one LDS atomic per candidate ranks it within its column, ONE returning
+    // global atomic per column reserves room, then the keys are stored.  The returning atomic sits in the same in-order queue
+    // as the stage loads, so waiting for it drains the three stages in flight: the flush is synchronous but RARE -- a wave
+    // parks ~1.5 candidates per stage and flushes when half the parking area is used (every ~20 stages).
+    uint32_t n_park = 0;                                                        // wave-uniform
+    const uint32_t my_col_slot = __float_as_uint(colc[lane].z);                 // lane c: query slot of column c
+    auto flush = [&]() {
+        pk_n[lane] = 0u;
+        wave_fence();
+        uint32_t rank_in_col = 0;
+        if ((uint32_t) lane < n_park) rank_in_col = atomicAdd(&pk_n[pk_c[lane]], 1u);      // LDS
+        wave_fence();
+        const uint32_t mine = pk_n[lane];
+        uint32_t fl_base = 0;
+        if (mine) fl_base = atomicAdd(p.qcnt + my_col_slot, mine);
+        const uint32_t c = (uint32_t) lane < n_park ? pk_c[lane] : 0u;
+        const uint32_t base = (uint32_t) __shfl((int) fl_base, (int) c);
+        const uint32_t slot = (uint32_t) __shfl((int) my_col_slot, (int) c);
+        if ((uint32_t) lane < n_park) {
+            const uint32_t at = base + rank_in_col;
+            const uint32_t row = pk_r[lane];
+            if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = ((uint64_t) pk_v[lane] << 32) | (g_rank ? g_rank[row] : row);
+        }
+        n_park = 0;
+        wave_fence();
+    };
+
+    // ---- prologue: descriptors of chunks 0 and 1, permission words of chunk 0, three stages in flight ----
+    fetch_desc(0);
+    fetch_desc(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fetch_words(0);
+    issue(0);
+    issue(1);
+    issue(2);
+
+    for (uint32_t i = 0; i < n_w; ++i) {
+        const uint32_t c = i / KI_CHUNK;
+        // stage i has landed when at most the ten operations of stages i + 1 and i + 2 are outstanding (anything else in the
+        // queue -- a chunk's mapping loads, a reservation -- only makes this wait for a little more than it needs)
+        const uint32_t ph = i % KI_CHUNK;
+        if (ph == 1 || ph == 2) {                                              // the chunk's mapping loads are in between: count them
+            if (has_bitmap) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if (ph == 0) {                                               // chunk c + 1's words, chunk c + 2's descriptors
+            fetch_words(c + 1);
+            fetch_desc(c + 2);
+        }
+        issue(i + 3);                                                           // into the slot stage i - 1 was multiplied from
+
+        // ---- this stage's rows: validity, thresholds ----
+        const uint32_t e = (i % KI_CHUNK) * 2u;
+        const uint32_t tb = t0 + 2u * ((uint32_t) wave + 4u * i);
+        const uint2 dd[2] = {desc_of(c, e, tb), desc_of(c, e + 1u, tb + 1u)};
+        const uint32_t slot_ = i & (KI_SLOTS - 1);
+        const float* nrm = nring + slot_ * KI_ROWS;
+        if (lane < KI_ROWS) {
+            const uint2 d = lane < 16 ? dd[0] : dd[1];
+            const uint32_t o = (uint32_t) lane & 15u;
+            const uint32_t r = d.x + o;
+            bool ok = o < d.y && r <= last_row;
+            bad_row |= o < d.y && r > last_row;
+            if (has_bitmap) {
+                const uint32_t* w = wring + (c & 1u) * (4 * CT) + e + ((uint32_t) lane >> 4);
+                const uint32_t r0 = d.x <= last_row ? d.x : last_row;
+                const uint32_t bit = r - ((r0 >> 6) << 6);                      // 0 .. 78: inside the two-word window
+                const uint32_t word = w[(bit >> 5) * CT];
+                ok = ok && ((word >> (bit & 31u)) & 1u);
+            }
+            thr[lane] = ok ? ((int32_t) nrm[lane]) >> 1 : 0x7FFFFFFF;
+        }
+
+        // ---- 2 row blocks x NQG query groups x 2 k-steps ----
+        i32x4 acc[2][NQG];
+        const uint4* img = ring + (size_t) slot_ * KI_STAGE_U4;
+        i32x4 a8[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = rb * 16 + li;
+                a8[rb][ks] = __builtin_bit_cast(i32x4, img[row * 8 + ((ks * 4 + kq) ^ ((row >> 1) & 7))]);
+            }
+#pragma unroll
+        for (int j = 0; j < NQG; ++j) {
+            if ((uint32_t) j < ngt) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    acc[rb][j] = i32x4{c0j[j], c0j[j], c0j[j], c0j[j]};
+                    acc[rb][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a8[rb][0], b8[j][0], acc[rb][j], 0, 0, 0);
+                    acc[rb][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a8[rb][1], b8[j][1], acc[rb][j], 0, 0, 0);
+                }
+            } else {
+                acc[0][j] = i32x4{-0x40000000, -0x40000000, -0x40000000, -0x40000000};
+                acc[1][j] = acc[0][j];
+            }
+        }
+
+        // ---- epilogue: acc[rb][j][r] = row rb * 16 + kq * 4 + r of the stage, query column j * 16 + li ----
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const i32x4 th = __builtin_bit_cast(i32x4, reinterpret_cast<const uint4*>(thr)[rb * 4 + kq]);
+            const int32_t th4[4] = {th[0], th[1], th[2], th[3]};
+            uint64_t m[NQG][4];
+            uint64_t any = 0;
+#pragma unroll
+            for (int j = 0; j < NQG; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m[j][r] = __ballot(acc[rb][j][r] >= th4[r]);
+                    any |= m[j][r];
+                }
+            if (any) {
+#pragma unroll
+                for (int j = 0; j < NQG; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint64_t cm = m[j][r];
+                        if (!cm) continue;                                      // scalar test
+                        const bool has = (cm >> lane) & 1ull;
+                        const uint32_t o = (uint32_t) (kq * 4 + r);
+                        const uint32_t row = dd[rb].x + o;
+                        const f32x4 cc = __builtin_bit_cast(f32x4, reinterpret_cast<const uint4*>(colc)[j * 16 + li]);
+                        const f32x4 nx4 = __builtin_bit_cast(f32x4, reinterpret_cast<const uint4*>(nrm)[rb * 4 + kq]);
+                        const float v = screen_value<M_L2>((float) (acc[rb][j][r] - c0j[j]), nx4[r], cc[1]);
+                        const uint32_t at = n_park + __builtin_amdgcn_mbcnt_hi((uint32_t) (cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) cm, 0u));
+                        if (has) {
+                            if (at < (uint32_t) KI_PARK) {
+                                pk_v[at] = mono_bits(v);
+                                pk_r[at] = row;
+                                pk_c[at] = (uint32_t) (j * 16 + li);
+                            } else {                                            // a burst beyond the parking area: directly
+                                const uint32_t slot = __float_as_uint(cc[2]);
+                                const uint32_t ga = atomicAdd(p.qcnt + slot, 1u);
+                                if (ga < p.capq)
+                                    p.qcand[(size_t) slot * p.capq + ga] = ((uint64_t) mono_bits(v) << 32) | (g_rank ? g_rank[row] : row);
+                            }
+                        }
+                        n_park += (uint32_t) __popcll(cm);
+                        if (n_park > (uint32_t) KI_PARK) n_park = KI_PARK;
+                    }
+            }
+        }
+        if (n_park >= (uint32_t) KI_FLUSH_AT) flush();
+    }
+    if (n_park) flush();
+    if (bad_row) atomicOr(p.err, 1u);                                           // a tile reached past the corpus: results invalid
+    // the stages still in flight write LDS: they must have landed before the workgroup gives its LDS back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+inline hipError_t launch_i8_stream(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
+{
+    if (p.plane_ho != 2 || p.pstride4 != 8 || p.rw != 16 || p.sample_stride > 1 || p.qmax > (uint32_t) KI_NQ || !p.ones)
+        return hipErrorInvalidValue;
+    const size_t lds = i8s_lds_bytes();
+    auto kern = i8_stream_kernel<4>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(KI_THREADS), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace vsr

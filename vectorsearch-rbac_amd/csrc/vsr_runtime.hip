@@ -178,6 +178,9 @@ struct vsr_ctx {
     bool no_mq = false;            // VSR_NO_MQ=1: keep shared passes on K1 (A/B measurements)
     bool no_wide = false;          // VSR_NO_WIDE=1: shared passes on K2 (wave-private tiles) instead of K2w (A/B)
     bool no_gemm = false;          // VSR_NO_GEMM=1: wide passes over long rows on K2w instead of K2g (A/B)
+    bool no_k2i = false;           // VSR_NO_K2I=1: the int8 main launch on K2w's workgroup tiles instead of K2i's wave streams (A/B)
+    bool last_k2i = false;         // the last main launch was eligible for K2i
+    int  force_epi = -1;           // VSR_FORCE_EPI=0|1: the main launch's survivor handling regardless of the estimate (tests)
     int  screen_level = 2;         // search_impl -> make_plan: 2 = every screening tier, 1 = no coarse tier (K2g), 0 = exact only
     bool last_coarse = false;      // the last search screened on the coarse planes: its flagged queries go to the fine tier first
 
@@ -324,6 +327,8 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_NO_MQ"))) ctx->no_mq = atoi(env) != 0;
     if ((env = getenv("VSR_NO_WIDE"))) ctx->no_wide = atoi(env) != 0;
     if ((env = getenv("VSR_NO_GEMM"))) ctx->no_gemm = atoi(env) != 0;
+    if ((env = getenv("VSR_NO_K2I"))) ctx->no_k2i = atoi(env) != 0;
+    if ((env = getenv("VSR_FORCE_EPI"))) ctx->force_epi = atoi(env) != 0;
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
@@ -1562,13 +1567,15 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // the instantiation the main scan launch of a plan resolves to (bench.py reports it beside the roofline)
-static std::string scan_kernel_name(const Plan& plan, const vsr_corpus* c, int metric)
+static std::string scan_kernel_name(const Plan& plan, const vsr_corpus* c, int metric, bool k2i = false)
 {
     static const char* mname[] = {"L2", "IP", "COSINE", "L1"};
     char buf[160];
     const uint32_t nstage = (c->stride4 + 15) / 16;
     if (plan.k2g)
         snprintf(buf, sizeof buf, "vsr::gemm_screen_kernel<%s, SAMPLE=false> (K2g, bf16 coarse planes)", mname[metric]);
+    else if (plan.k2w && plan.int8 && k2i)
+        snprintf(buf, sizeof buf, "vsr::i8_stream_kernel<NQG=4> (K2i, int8 planes, %s)", mname[metric]);
     else if (plan.k2w && plan.int8)
         snprintf(buf, sizeof buf, "vsr::mfma_wide_kernel<%s, NCH=1, SAMPLE=false, PL=int8> (K2w, int8 planes)", mname[metric]);
     else if (plan.k2w)
@@ -1768,6 +1775,9 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
             const double rows_per_query = (double) plan.scan_pairs / std::max(1, nq);
             sp.epi = rows_per_query > 0 && 1024.0 * admitted / rows_per_query <= 4.0 ? 1u : 0u;
         }
+        if (ctx->force_epi >= 0) sp.epi = (uint32_t) ctx->force_epi;
+        sp.k2i = plan.int8 && !plan.k2g && sp.epi == 1 && !ctx->no_k2i && sp.rw == 16 && sp.qmax <= 64 ? 1u : 0u;
+        ctx->last_k2i = sp.k2i != 0;
         sp.tau_init = ctx->d_tau.as<uint64_t>();
         sp.qcand = ctx->d_cand.as<uint64_t>();
         sp.qcnt = qcnt;
@@ -1778,7 +1788,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
             HIPCHK(hipEventRecord(e1, ctx->stream));
             ctx->pending.push_back({e0, e1, 1});
         }
-        ctx->last_kernel = scan_kernel_name(plan, c, metric);
+        ctx->last_kernel = scan_kernel_name(plan, c, metric, ctx->last_k2i);
         ctx->stats.scan_bytes[1] += plan.scan_bytes;
         ctx->stats.scan_rows[1] += plan.scan_rows;
         ctx->stats.scan_pairs[1] += plan.scan_pairs;
