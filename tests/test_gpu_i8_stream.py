@@ -5,8 +5,8 @@ The planner picks the mask epilogue (and with it K2i) only when it expects few s
 VSR_FORCE_EPI=1 selects it for the small corpora of this file.  Covered: ragged list tiles (documents of 37 rows: 16 + 16
 + 5), RANGES and BITMAP filters (the permission bit tested per row inside the two-word window), passes of 1..64 queries
 and more than 64 (several passes), workgroups whose waves get 0, 1 or many stages, an unfiltered identity list, thresholds
-that stay open (a filter that fits the candidate buffer), and the same searches with VSR_NO_K2I=1 (K2w) returning the
-same bytes."""
+that stay open (a filter that fits the candidate buffer), and the same searches on K2w (the default) returning the same
+bytes.  K2i is opt-in (VSR_K2I=1) while it is the slower of the two on the headline step."""
 import numpy as np
 import pytest
 
@@ -55,7 +55,7 @@ def test_k2i_matches_oracle_and_k2w(oracle, monkeypatch, mode):
     q[:, :5] = rng.integers(0, 256, (nq, 5)).astype(np.float32)
     masks = [None if r < 0 else row_masks[r] for r in role_of]
     results = {}
-    for label, env in (("k2i", {"VSR_FORCE_EPI": "1"}), ("k2w", {"VSR_FORCE_EPI": "1", "VSR_NO_K2I": "1"})):
+    for label, env in (("k2i", {"VSR_FORCE_EPI": "1", "VSR_K2I": "1"}), ("k2w", {"VSR_FORCE_EPI": "1"})):
         ctx = _ctx(monkeypatch, **env)
         corpus = ctx.load_corpus(x, blk, doc)
         fmode = vsrbac.RANGES if mode == "ranges" else vsrbac.BITMAP
@@ -81,7 +81,7 @@ def test_k2i_short_streams_and_device_api(oracle, monkeypatch):
     u8 query hint: counts are never negative (int8 screening is exact: nothing to flag)."""
     import torch
     rng = np.random.default_rng(616)
-    ctx = _ctx(monkeypatch, VSR_FORCE_EPI="1", VSR_MIN_ROWS_PER_BLOCK="16")
+    ctx = _ctx(monkeypatch, VSR_FORCE_EPI="1", VSR_K2I="1", VSR_MIN_ROWS_PER_BLOCK="16")
     ctx.set_query_hint(True)
     for n in (700, 5_000, 40_000):
         dim, k, nq = 96, 10, 40                                        # d = 96: rows padded to 128 int8 elements

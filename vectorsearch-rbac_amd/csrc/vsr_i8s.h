@@ -99,6 +99,31 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
     uint32_t* pk_n = pk_c + KI_PARK;                                            // [64] candidates per column
     float4*   colc = reinterpret_cast<float4*>(smem + KI_WAVES * KI_WAVE_BYTES);   // [64] {c0 bits, |q|^2, slot bits, -}
 
+    // ---- this wave's stages: stage i of the wave = list tiles t0 + 2 (wave + 4 i) + {0, 1} of the workgroup's range ----
+    const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
+    const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
+    const uint32_t n_st = (t1 - t0 + 1u) >> 1;
+    const uint32_t n_w = n_st > (uint32_t) wave ? (n_st - (uint32_t) wave + 3u) >> 2 : 0u;
+    const uint32_t tile_last = grp.n_tiles - 1u;
+    const uint32_t last_row = p.n_rows - 1u;
+
+    // list tile J (0 .. ) of mapping chunk c, as this wave numbers them: stage KI_CHUNK c + (J >> 1), half J & 1
+    auto tile_of = [&](uint32_t c, uint32_t J) -> uint32_t { return t0 + 2u * ((uint32_t) wave + 4u * (c * KI_CHUNK + (J >> 1))) + (J & 1u); };
+    auto fetch_desc = [&](uint32_t c) {                                        // chunk c's descriptors -> LDS (lane L < CT: tile L)
+        if ((uint32_t) lane >= CT) return;
+        const uint32_t t = tile_of(c, (uint32_t) lane);
+        const gptr<uint32_t> src = (gptr<uint32_t>) (g_tiles + (t < tile_last ? t : tile_last));
+        uint32_t* dst = dring + (c % 3u) * (2 * CT);
+        __builtin_amdgcn_global_load_lds(src, (lds_u32*) dst, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 1, (lds_u32*) dst + CT, 4, 0, 0);
+    };
+    // The first two chunks' descriptors are requested before anything else: their latency runs under the query columns' and
+    // the B fragments' loads (a wave lives ~30 stages; every serialised round trip of the prologue is ~5 % of it).
+    if (n_w) {
+        fetch_desc(0);
+        fetch_desc(1);
+    }
+
     // ---- query columns: the thresholds folded into what the integer accumulators start from (vsr_mfmaw.h, ITEST) ----
     if (tid < KI_NQ) {
         const bool qok = (uint32_t) tid < q_count;
@@ -111,6 +136,7 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
         colc[tid] = make_float4(__int_as_float(c0), qn, __uint_as_float(qok ? slot : 0xFFFFFFFFu), 0.0f);
     }
     __syncthreads();
+    if (n_w == 0) return;                                                       // (after the only workgroup barrier)
 
     // MFMA lane roles (16x16x64 int8): A lane = (row li, 16-byte k-chunk kq); B / result lane = (k-chunk kq | row quad kq, query li)
     const int li = lane & 15;
@@ -132,35 +158,16 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
 #pragma unroll
     for (int j = 0; j < NQG; ++j) asm volatile("" : "+v"(b8[j][0]), "+v"(b8[j][1]), "+v"(c0j[j]));
 
-    // ---- this wave's stages: stage i of the wave = list tiles t0 + 2 (wave + 4 i) + {0, 1} of the workgroup's range ----
-    const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
-    const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
-    const uint32_t n_st = (t1 - t0 + 1u) >> 1;
-    const uint32_t n_w = n_st > (uint32_t) wave ? (n_st - (uint32_t) wave + 3u) >> 2 : 0u;
-    if (n_w == 0) return;                                                       // (after the only workgroup barrier)
-    const uint32_t tile_last = grp.n_tiles - 1u;
-    const uint32_t last_row = p.n_rows - 1u;
-
-    // mapping chunk c -> LDS: lane L < CT holds list tile (stage KI_CHUNK c + (L >> 1), half L & 1)
-    auto chunk_tile = [&](uint32_t c) -> uint32_t { return t0 + 2u * ((uint32_t) wave + 4u * (c * KI_CHUNK + ((uint32_t) lane >> 1))) + ((uint32_t) lane & 1u); };
-    auto fetch_desc = [&](uint32_t c) {
-        if ((uint32_t) lane >= CT) return;
-        const uint32_t t = chunk_tile(c);
-        const gptr<uint32_t> src = (gptr<uint32_t>) (g_tiles + (t < tile_last ? t : tile_last));
-        uint32_t* dst = dring + (c % 3u) * (2 * CT);
-        __builtin_amdgcn_global_load_lds(src, (lds_u32*) dst, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds(src + 1, (lds_u32*) dst + CT, 4, 0, 0);
-    };
-    // (start row, rows) of a chunk's list tile as this wave sees it: tiles past the workgroup's range hold no rows
-    auto desc_of = [&](uint32_t c, uint32_t idx, uint32_t t) -> uint2 {
-        const uint32_t* d = dring + (c % 3u) * (2 * CT);
-        const bool ok = t < t1;
-        return make_uint2(ok ? d[idx] : 0u, ok ? d[CT + idx] : 0u);
+    // first row of tile J of chunk c (0 for a tile past the workgroup's range: its loads read rows 0 .. 15, nobody uses them)
+    auto desc_x = [&](uint32_t c, uint32_t J) -> uint32_t {
+        if (J >= CT) { c += 1u; J -= CT; }
+        const uint32_t x = dring[(c % 3u) * (2 * CT) + J];
+        return tile_of(c, J) < t1 ? x : 0u;
     };
     auto fetch_words = [&](uint32_t c) {                                       // needs chunk c's descriptors in LDS
         if (!has_bitmap || (uint32_t) lane >= CT) return;
-        const uint2 d = desc_of(c, (uint32_t) lane, chunk_tile(c));
-        const uint32_t r0 = d.x <= last_row ? d.x : last_row;
+        const uint32_t x = desc_x(c, (uint32_t) lane);
+        const uint32_t r0 = x <= last_row ? x : last_row;
         const gptr<uint32_t> src = (gptr<uint32_t>) (g_bitmap + (r0 >> 6));    // (bitmaps carry two pad words: the window never leaves them)
         uint32_t* dst = wring + (c & 1u) * (4 * CT);
         __builtin_amdgcn_global_load_lds(src, (lds_u32*) dst, 4, 0, 0);
@@ -169,29 +176,28 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
         __builtin_amdgcn_global_load_lds(src + 3, (lds_u32*) dst + 3 * CT, 4, 0, 0);
     };
 
-    // rows + |row|^2 of stage i into ring slot i & 3: four 1-KB pieces (8 rows x 128 bytes) and one 128-byte norm piece.  Always
-    // five operations, also past the wave's last stage (row 0, never used), so that the counted wait below is exact.
-    bool bad_row = false;
-    auto issue = [&](uint32_t i) {
-        const uint32_t c = i / KI_CHUNK, e = (i % KI_CHUNK) * 2u;
-        const uint32_t tb = t0 + 2u * ((uint32_t) wave + 4u * i);
-        const uint2 d0 = desc_of(c, e, tb), d1 = desc_of(c, e + 1u, tb + 1u);
+    // The loads of a stage: four 1-KB pieces (8 rows x 128 bytes: list tile 0 rows 0-7, 8-15, list tile 1 rows 0-7, 8-15) and one
+    // 128-byte piece of |row|^2.  A list tile's 16 rows are consecutive, so a piece is (wave-uniform base of the tile) + (a
+    // lane constant): the lane's row within the tile and its swizzled chunk.  Whole tiles are loaded whatever their row count
+    // (rows past it are masked by their threshold; the planes and norms are padded so that a tile may start at the last row).
+    uint32_t voff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t rit = (uint32_t) (h * 8) + ((uint32_t) lane >> 3);
+        voff[h] = (rit * 8u + (((uint32_t) lane & 7u) ^ ((rit >> 1) & 7u))) * 16u;
+    }
+    const uint32_t noff = (uint32_t) lane & 15u;
+    auto issue = [&](uint32_t i, uint32_t x0, uint32_t x1) {                   // x0, x1: wave-uniform first rows of the two tiles
         const uint32_t slot_ = i & (KI_SLOTS - 1);
         lds_u4* dst = (lds_u4*) (ring + (size_t) slot_ * KI_STAGE_U4);
-#pragma unroll
-        for (int pc = 0; pc < 4; ++pc) {
-            const uint2 d = pc < 2 ? d0 : d1;
-            const uint32_t o = (uint32_t) ((pc & 1) * 8) + ((uint32_t) lane >> 3);
-            uint32_t row = d.x + (o < d.y ? o : 0u);
-            row = row <= last_row ? row : last_row;
-            const uint32_t ch = ((uint32_t) lane & 7u) ^ (((uint32_t) (pc * 4) + ((uint32_t) lane >> 4)) & 7u);
-            __builtin_amdgcn_global_load_lds(as_global(p.scr + (size_t) row * 8u + ch), dst + pc * 64, 16, 0, 0);
-        }
+        const char* b0 = reinterpret_cast<const char*>(p.scr) + (size_t) x0 * 128u;
+        const char* b1 = reinterpret_cast<const char*>(p.scr) + (size_t) x1 * 128u;
+        __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const uint4*>(b0 + voff[0])), dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const uint4*>(b0 + voff[1])), dst + 64, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const uint4*>(b1 + voff[0])), dst + 128, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(as_global(reinterpret_cast<const uint4*>(b1 + voff[1])), dst + 192, 16, 0, 0);
         if (lane < KI_ROWS) {
-            const uint2 d = lane < 16 ? d0 : d1;
-            const uint32_t o = (uint32_t) lane & 15u;
-            uint32_t row = d.x + (o < d.y ? o : 0u);
-            row = row <= last_row ? row : last_row;
+            const uint32_t row = (lane < 16 ? x0 : x1) + noff;
             __builtin_amdgcn_global_load_lds((gptr<uint32_t>) (g_norm2 + row), (lds_u32*) (nring + slot_ * KI_ROWS), 4, 0, 0);
         }
     };
@@ -223,52 +229,68 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
         wave_fence();
     };
 
+    // ---- mapping state of the current chunk, one list tile per lane (L < CT) ----
+    uint32_t cx = 0;       // compute side: first row of tile L
+    uint32_t cm = 0;       //               its validity mask: bit o = row o exists and is permitted
+    uint32_t ix = 0;       // issue side: first row of tile L + 6 (the stage three ahead of tile L's)
+    bool bad_row = false;
+    auto enter_chunk = [&](uint32_t c) {                                       // chunk c's and c + 1's descriptors, chunk c's words are in LDS
+        const uint32_t L = (uint32_t) lane & (CT - 1u);
+        const uint32_t* d = dring + (c % 3u) * (2 * CT);
+        const bool tile_ok = tile_of(c, L) < t1;
+        const uint32_t x = tile_ok ? d[L] : 0u;
+        const uint32_t y = tile_ok ? d[CT + L] : 0u;
+        uint32_t m = y >= 16u ? 0xFFFFu : (1u << y) - 1u;
+        if (y && x + y - 1u > last_row) {                                      // cannot happen: reported once at the end
+            bad_row = true;
+            m = 0;
+        }
+        if (has_bitmap) {
+            const uint32_t* w = wring + (c & 1u) * (4 * CT) + L;
+            const uint32_t r0 = x <= last_row ? x : last_row;
+            const uint32_t b0 = r0 & 63u;                                       // the window starts at the word that holds row x
+            const uint32_t lo = w[(b0 >> 5) * CT], hi = w[((b0 >> 5) + 1u) * CT];
+            m &= (uint32_t) ((((uint64_t) hi << 32) | lo) >> (b0 & 31u));
+        }
+        cx = x;
+        cm = m;
+        ix = desc_x(c, L + 6u);
+    };
+
     // ---- prologue: descriptors of chunks 0 and 1, permission words of chunk 0, three stages in flight ----
-    fetch_desc(0);
-    fetch_desc(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fetch_words(0);
-    issue(0);
-    issue(1);
-    issue(2);
+    {
+        const uint32_t px = desc_x(0, (uint32_t) lane & (CT - 1u));
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+            issue((uint32_t) s3, (uint32_t) __builtin_amdgcn_readlane((int) px, 2 * s3), (uint32_t) __builtin_amdgcn_readlane((int) px, 2 * s3 + 1));
+    }
 
     for (uint32_t i = 0; i < n_w; ++i) {
-        const uint32_t c = i / KI_CHUNK;
-        // stage i has landed when at most the ten operations of stages i + 1 and i + 2 are outstanding (anything else in the
-        // queue -- a chunk's mapping loads, a reservation -- only makes this wait for a little more than it needs)
         const uint32_t ph = i % KI_CHUNK;
-        if (ph == 1 || ph == 2) {                                              // the chunk's mapping loads are in between: count them
+        // stage i has landed when at most the ten operations of stages i + 1 and i + 2 are outstanding (anything else in the
+        // queue -- a flush's stores -- only makes this wait for a little more than it needs); right after a chunk boundary
+        // that chunk's mapping loads sit in between and are counted too
+        if (ph == 1 || ph == 2) {
             if (has_bitmap) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         } else
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        if (ph == 0) {                                               // chunk c + 1's words, chunk c + 2's descriptors
+        if (ph == 0) {
+            const uint32_t c = i / KI_CHUNK;
+            enter_chunk(c);
             fetch_words(c + 1);
             fetch_desc(c + 2);
         }
-        issue(i + 3);                                                           // into the slot stage i - 1 was multiplied from
+        const int e = (int) (ph * 2u);
+        issue(i + 3, (uint32_t) __builtin_amdgcn_readlane((int) ix, e), (uint32_t) __builtin_amdgcn_readlane((int) ix, e + 1));
 
-        // ---- this stage's rows: validity, thresholds ----
-        const uint32_t e = (i % KI_CHUNK) * 2u;
-        const uint32_t tb = t0 + 2u * ((uint32_t) wave + 4u * i);
-        const uint2 dd[2] = {desc_of(c, e, tb), desc_of(c, e + 1u, tb + 1u)};
+        // ---- thresholds of this stage's rows: floor(|row|^2 / 2), INT_MAX for a row that does not exist or is not permitted ----
         const uint32_t slot_ = i & (KI_SLOTS - 1);
         const float* nrm = nring + slot_ * KI_ROWS;
-        if (lane < KI_ROWS) {
-            const uint2 d = lane < 16 ? dd[0] : dd[1];
-            const uint32_t o = (uint32_t) lane & 15u;
-            const uint32_t r = d.x + o;
-            bool ok = o < d.y && r <= last_row;
-            bad_row |= o < d.y && r > last_row;
-            if (has_bitmap) {
-                const uint32_t* w = wring + (c & 1u) * (4 * CT) + e + ((uint32_t) lane >> 4);
-                const uint32_t r0 = d.x <= last_row ? d.x : last_row;
-                const uint32_t bit = r - ((r0 >> 6) << 6);                      // 0 .. 78: inside the two-word window
-                const uint32_t word = w[(bit >> 5) * CT];
-                ok = ok && ((word >> (bit & 31u)) & 1u);
-            }
-            thr[lane] = ok ? ((int32_t) nrm[lane]) >> 1 : 0x7FFFFFFF;
-        }
+        const uint32_t m32 = (uint32_t) __builtin_amdgcn_readlane((int) cm, e) | ((uint32_t) __builtin_amdgcn_readlane((int) cm, e + 1) << 16);
+        if (lane < KI_ROWS) thr[lane] = (m32 >> lane) & 1u ? ((int32_t) nrm[lane]) >> 1 : 0x7FFFFFFF;
 
         // ---- 2 row blocks x NQG query groups x 2 k-steps ----
         i32x4 acc[2][NQG];
@@ -290,9 +312,6 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
                     acc[rb][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a8[rb][0], b8[j][0], acc[rb][j], 0, 0, 0);
                     acc[rb][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a8[rb][1], b8[j][1], acc[rb][j], 0, 0, 0);
                 }
-            } else {
-                acc[0][j] = i32x4{-0x40000000, -0x40000000, -0x40000000, -0x40000000};
-                acc[1][j] = acc[0][j];
             }
         }
 
@@ -300,30 +319,36 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const i32x4 th = __builtin_bit_cast(i32x4, reinterpret_cast<const uint4*>(thr)[rb * 4 + kq]);
-            const int32_t th4[4] = {th[0], th[1], th[2], th[3]};
             uint64_t m[NQG][4];
             uint64_t any = 0;
 #pragma unroll
             for (int j = 0; j < NQG; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    m[j][r] = __ballot(acc[rb][j][r] >= th4[r]);
-                    any |= m[j][r];
+                for (int r = 0; r < 4; ++r) m[j][r] = 0;
+#pragma unroll
+            for (int j = 0; j < NQG; ++j)
+                if ((uint32_t) j < ngt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        m[j][r] = __ballot(acc[rb][j][r] >= th[r]);
+                        any |= m[j][r];
+                    }
                 }
             if (any) {
+                const uint32_t x_rb = (uint32_t) __builtin_amdgcn_readlane((int) cx, e + rb);
 #pragma unroll
                 for (int j = 0; j < NQG; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const uint64_t cm = m[j][r];
-                        if (!cm) continue;                                      // scalar test
-                        const bool has = (cm >> lane) & 1ull;
+                        const uint64_t cmk = m[j][r];
+                        if (!cmk) continue;                                     // scalar test
+                        const bool has = (cmk >> lane) & 1ull;
                         const uint32_t o = (uint32_t) (kq * 4 + r);
-                        const uint32_t row = dd[rb].x + o;
+                        const uint32_t row = x_rb + o;
                         const f32x4 cc = __builtin_bit_cast(f32x4, reinterpret_cast<const uint4*>(colc)[j * 16 + li]);
                         const f32x4 nx4 = __builtin_bit_cast(f32x4, reinterpret_cast<const uint4*>(nrm)[rb * 4 + kq]);
                         const float v = screen_value<M_L2>((float) (acc[rb][j][r] - c0j[j]), nx4[r], cc[1]);
-                        const uint32_t at = n_park + __builtin_amdgcn_mbcnt_hi((uint32_t) (cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) cm, 0u));
+                        const uint32_t at = n_park + __builtin_amdgcn_mbcnt_hi((uint32_t) (cmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) cmk, 0u));
                         if (has) {
                             if (at < (uint32_t) KI_PARK) {
                                 pk_v[at] = mono_bits(v);
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
                                     p.qcand[(size_t) slot * p.capq + ga] = ((uint64_t) mono_bits(v) << 32) | (g_rank ? g_rank[row] : row);
                             }
                         }
-                        n_park += (uint32_t) __popcll(cm);
+                        n_park += (uint32_t) __popcll(cmk);
                         if (n_park > (uint32_t) KI_PARK) n_park = KI_PARK;
                     }
             }
