@@ -248,6 +248,13 @@ int vsr_hnsw_search(vsr_hnsw* index, const float* queries, int nq, int dim, int 
 /* same, queries (nq x dim floats, row stride dim) and outputs in device memory, enqueued on the corpus context's stream in
  * ONE launch, no synchronisation.  On graphs beyond ~1M elements the visited set is a table in LDS sized by ef_search; a
  * query that outgrows it reports count -1 (never a partial result): vsr_hnsw_search re-runs such queries itself. */
+/* index build (hnswbuild.c:357-470 in-memory build; hnswutils.c:1053-1346): batched insertion on the GPU over the corpus's rows
+ * with m and ef_construction as the reloptions define them, levels from a seeded xorshift64* stream.  The
+ * graph is not the serial build's graph -- neither is the reference's own parallel build's -- the guarantee is recall
+ * (pgvector's test/t/012_hnsw_vector_build_recall.pl thresholds; tests/test_gpu_index.py).  Identical vectors are not merged
+ * into one element (hnswbuild.c:329-351): every row is its own element.  Synchronises. */
+int vsr_hnsw_build(vsr_corpus* corpus, int m, int ef_construction, int metric, uint64_t seed, vsr_hnsw** out);
+int vsr_hnsw_info(const vsr_hnsw* index, int32_t* n_elem, int32_t* entry, int32_t* entry_level, int32_t* max_level);
 int vsr_hnsw_search_device(vsr_hnsw* index, const float* d_queries, int nq, int dim, int k, int ef_search, int metric,
                            const vsr_filter* const* filters,
                            int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows, float* d_out_dist,

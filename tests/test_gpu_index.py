@@ -410,3 +410,60 @@ def test_ivf_kmeans_spherical_variant(ctx, oracle):
     got, _ = ctx.ivf_kmeans(samples, lists, "cosine", seed=3)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
     np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# f2: HNSW build on the GPU (vsr_hnsw_build: batched insertion).  Graph identity is not reproducible even in the reference
+# (its parallel build races), so parity = recall: pgvector's own TAP case and thresholds
+# (pgvector/test/t/012_hnsw_vector_build_recall.pl: 10 000 rows of 3-d random() * random(), 20 queries, LIMIT 20, default m,
+# ef_construction, ef_search; >= 0.99, inner product >= 0.97), and recall within 0.01 of the index oracle's serial build.
+# ---------------------------------------------------------------------------------------------
+def _recall(found_rows, exact_rows):
+    hit = sum(len(set(f.tolist()) & set(e.tolist())) for f, e in zip(found_rows, exact_rows))
+    return hit / sum(len(e) for e in exact_rows)
+
+
+@pytest.mark.parametrize("metric,floor", [("l2", 0.99), ("ip", 0.97), ("cosine", 0.99)])
+def test_hnsw_build_on_the_gpu_recall_parity_tap_case(ctx, oracle, metric, floor):
+    rng = np.random.default_rng(1201)
+    n, k = 10_000, 20
+    x = (rng.random((n, 3)) * rng.random((n, 3))).astype(np.float32)
+    q = rng.random((20, 3)).astype(np.float32)
+    if metric == "cosine":                                                 # the opclass ranks unit vectors by inner product
+        x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    corpus = ctx.load_corpus(x)
+    exact = corpus.search(q, k, metric).rows
+    gpu = corpus.build_hnsw(16, 64, metric, seed=3)
+    n_elem, entry, entry_level, max_level = gpu.info()
+    assert n_elem == n and 0 <= entry < n and 1 <= entry_level <= max_level
+    got, _ = gpu.search(q, k, 40, metric)
+    r_gpu = _recall([got.rows[i][:got.counts[i]] for i in range(len(q))], exact)
+    ref = OracleHnsw(oracle, metric, x, m=16, ef_construction=64, seed=3)
+    r_ref = _recall([ref.search(q[i], 40)[0][:k] for i in range(len(q))], exact)
+    print(f"hnsw build {metric}: recall@20 GPU batched {r_gpu:.4f}, serial port {r_ref:.4f}")
+    assert r_gpu >= floor, (r_gpu, r_ref)
+    assert r_gpu >= r_ref - 0.01, (r_gpu, r_ref)
+    gpu.free()
+    corpus.free()
+
+
+def test_hnsw_build_on_the_gpu_128d(ctx, oracle):
+    """SIFT-like 128-d rows: the batched build's graph answers like the serial port's at the same ef_search (recall within
+    0.02), its lists respect m / 2m, and every element but the first is reachable from layer 0 lists (no orphan lists)."""
+    rng = np.random.default_rng(1202)
+    n, dim, k = 20_000, 128, 10
+    x = np.clip(np.rint(np.abs(rng.normal(0, 45, (n, dim)))), 0, 255).astype(np.float32)
+    q = x[rng.integers(0, n, 50)] + rng.integers(-3, 4, (50, dim)).astype(np.float32)
+    corpus = ctx.load_corpus(x)
+    exact = corpus.search(q, k, "l2").rows
+    gpu = corpus.build_hnsw(16, 64, "l2", seed=5)
+    ref = OracleHnsw(oracle, "l2", x, m=16, ef_construction=64, seed=5)
+    for ef in (40, 200):
+        got, _ = gpu.search(q, k, ef, "l2")
+        r_gpu = _recall([got.rows[i][:got.counts[i]] for i in range(len(q))], exact)
+        r_ref = _recall([ref.search(q[i], ef)[0][:k] for i in range(len(q))], exact)
+        print(f"hnsw build 128-d ef={ef}: recall@10 GPU batched {r_gpu:.4f}, serial port {r_ref:.4f}")
+        assert r_gpu >= r_ref - 0.02, (ef, r_gpu, r_ref)
+    gpu.free()
+    corpus.free()

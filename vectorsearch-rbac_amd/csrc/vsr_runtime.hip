@@ -3,6 +3,7 @@
 #include "../../include/vsrbac.h"
 #include "vsr_device.h"
 #include "vsr_hnsw.h"
+#include "vsr_hnsw_build.h"
 
 #include <algorithm>
 #include <atomic>
@@ -2981,6 +2982,175 @@ extern "C" int vsr_hnsw_load(vsr_corpus* c, int m, int32_t n_elem, int32_t entry
     }
     c->hnsw_indexes.push_back(h.get());
     *out = h.release();
+    return VSR_OK;
+}
+
+// CREATE INDEX ... USING hnsw on the GPU (vsr_hnsw_build.hip): batched insertion over the corpus's rows (element e = internal
+// row e), levels from a seeded xorshift64* stream.  Returns a loaded index, as vsr_hnsw_load would from the same graph.
+extern "C" int vsr_hnsw_build(vsr_corpus* c, int m, int ef_construction, int metric, uint64_t seed, vsr_hnsw** out)
+{
+    if (!c || !out) return fail(VSR_ERR_INVALID, "vsr_hnsw_build: NULL argument");
+    *out = nullptr;
+    if (c->base) return fail(VSR_ERR_INVALID, "vsr_hnsw_build: the corpus is a view");
+    if (m < 2 || m > 100) return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_build: m must be between 2 and 100 (got %d)", m);
+    if (ef_construction < 4 || ef_construction > 1000 || ef_construction < 2 * m)      /* hnsw.c:62-63, hnswbuild.c:677-679 */
+        return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_build: ef_construction must be between 4 and 1000 and at least 2 * m (got %d)",
+                    ef_construction);
+    if (metric != VSR_METRIC_L2 && metric != VSR_METRIC_IP && metric != VSR_METRIC_COSINE)
+        return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_build: L2, inner product and cosine operator classes only");
+    vsr_ctx* ctx = c->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = c->n;
+    if (n > 0x7FFFFFF0ll) return fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_build: too many rows");
+    std::unique_ptr<vsr_hnsw> h(new vsr_hnsw());
+    h->corpus = c;
+    h->n_elem = (int32_t) n;
+    h->m = m;
+    // levels: level = floor(-ln(u) * ml), ml = 1 / ln(m) (hnswutils.c:243), capped like HnswGetMaxLevel (hnsw.h:89)
+    int cap = (8192 - 24 - 8 - 4 - 4) / 6 / m - 2;
+    cap = std::min(cap, 255);
+    uint64_t rs = seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;               // xorshift64* (the serial CPU restatement draws the same stream)
+    if (!rs) rs = 1;
+    auto next = [&]() {
+        uint64_t x = rs;
+        x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+        rs = x;
+        return x * 0x2545F4914F6CDD1DULL;
+    };
+    (void) next();
+    const double ml = 1.0 / std::log((double) m);
+    std::vector<int32_t> level((size_t) std::max<int64_t>(n, 1), 0), up_slot((size_t) std::max<int64_t>(n, 1), -1);
+    int32_t max_level = 1, n_upper = 0;
+    for (int64_t e = 0; e < n; ++e) {
+        const double u = (double) (next() >> 11) * (1.0 / 9007199254740992.0);
+        int lv = (int) (-std::log(u) * ml);
+        lv = std::min(lv, cap);
+        level[(size_t) e] = lv;
+        if (lv >= 1) {
+            up_slot[(size_t) e] = n_upper++;
+            max_level = std::max(max_level, lv);
+        }
+    }
+    h->max_level = max_level;
+    const size_t alloc = (size_t) std::max<int64_t>(n, 1);
+    float *d_dist0 = nullptr, *d_up_dist = nullptr;
+    uint64_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr};
+    uint32_t* d_cnt = nullptr;
+    void* d_tmp = nullptr;
+    auto cleanup = [&]() {
+        void* ptrs[] = {d_dist0, d_up_dist, d_key[0], d_key[1], d_val[0], d_val[1], d_cnt, d_tmp};
+        for (void* q : ptrs)
+            if (q) (void) hipFree(q);
+    };
+    auto bail = [&](int rc) {
+        cleanup();
+        vsr_hnsw_free(h.release());
+        return rc;
+    };
+#define HB_CHK(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return bail(fail(VSR_ERR_HIP, "vsr_hnsw_build: %s", hipGetErrorString(e_)));   \
+    } while (0)
+    const size_t up_words = (size_t) std::max(n_upper, 1) * max_level * m;
+    HB_CHK(hipMalloc(&h->d_level, alloc * 4));
+    HB_CHK(hipMalloc(&h->d_up_slot, alloc * 4));
+    HB_CHK(hipMalloc(&h->d_nbr0, alloc * 2 * m * 4));
+    HB_CHK(hipMalloc(&h->d_up_nbr, up_words * 4));
+    HB_CHK(hipMalloc(&d_dist0, alloc * 2 * m * 4));
+    HB_CHK(hipMalloc(&d_up_dist, up_words * 4));
+    HB_CHK(hipMemcpy(h->d_level, level.data(), alloc * 4, hipMemcpyHostToDevice));
+    HB_CHK(hipMemcpy(h->d_up_slot, up_slot.data(), alloc * 4, hipMemcpyHostToDevice));
+    HB_CHK(hipMemsetAsync(h->d_nbr0, 0xFF, alloc * 2 * m * 4, ctx->stream));
+    HB_CHK(hipMemsetAsync(h->d_up_nbr, 0xFF, up_words * 4, ctx->stream));
+
+    HnswBuildParams bp{};
+    bp.rows = c->d_rows;
+    bp.stride4 = c->stride4;
+    bp.metric = metric == VSR_METRIC_L2 ? M_L2 : M_IP;
+    bp.m = (uint32_t) m;
+    bp.efc = (uint32_t) ef_construction;
+    bp.max_level = (uint32_t) max_level;
+    bp.nbr0 = h->d_nbr0;
+    bp.dist0 = d_dist0;
+    bp.up_slot = h->d_up_slot;
+    bp.up_nbr = h->d_up_nbr;
+    bp.up_dist = d_up_dist;
+    bp.level = h->d_level;
+    bp.caps = (uint32_t) (ef_construction + 2 * m);
+    uint32_t slots = 4096;
+    while (slots < (uint32_t) ef_construction * 2u * (uint32_t) m * 2u && slots < 32768u) slots <<= 1;
+    bp.hash_slots = slots;
+    const size_t per = ((size_t) bp.caps * 8 + ((bp.caps + 15) & ~15u) + (size_t) HB_NBR * 12 + (size_t) bp.caps * 4 + (size_t) slots * 4 + 15) &
+                       ~(size_t) 15;
+    if (per > HN_LDS_BUDGET) return bail(fail(VSR_ERR_UNSUPPORTED, "vsr_hnsw_build: ef_construction = %d with m = %d does not fit the LDS", ef_construction, m));
+    bp.lds_per_wave = (uint32_t) per;
+    bp.wpb = (uint32_t) std::min<size_t>(4, HN_LDS_BUDGET / per);
+    bp.err = reinterpret_cast<uint32_t*>(ctx->d_flag_total) + 4;
+    const uint32_t batch_max = 4096;
+    bp.rec_cap = batch_max * (uint32_t) (2 * m + std::min(max_level, 4) * m);
+    HB_CHK(hipMalloc(&d_key[0], (size_t) bp.rec_cap * 8));
+    HB_CHK(hipMalloc(&d_key[1], (size_t) bp.rec_cap * 8));
+    HB_CHK(hipMalloc(&d_val[0], (size_t) bp.rec_cap * 8));
+    HB_CHK(hipMalloc(&d_val[1], (size_t) bp.rec_cap * 8));
+    HB_CHK(hipMalloc(&d_cnt, 64));
+    const size_t tmp_bytes = vsr_hnsw_build_sort_bytes(bp.rec_cap);
+    HB_CHK(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 256)));
+    bp.rec_count = d_cnt;
+
+    int32_t entry = -1, entry_level = -1;
+    for (int64_t done = 0; done < n;) {
+        // a batch never exceeds 1/8 of the graph it is inserted into: its elements do not see each other
+        const int64_t b = std::max<int64_t>(1, std::min<int64_t>({done / 8, (int64_t) batch_max, n - done}));
+        bp.entry = entry;
+        bp.entry_level = entry_level;
+        bp.first = (uint32_t) done;
+        bp.count = (uint32_t) b;
+        bp.rec_key = d_key[0];
+        bp.rec_val = d_val[0];
+        HB_CHK(vsr_hnsw_build_batch(bp, d_tmp, tmp_bytes, d_key[1], d_val[1], ctx->stream));
+        for (int64_t e = done; e < done + b; ++e)            // HnswUpdateGraphInMemory: a higher element becomes the entry point
+            if (entry < 0 || level[(size_t) e] > entry_level) {
+                entry = (int32_t) e;
+                entry_level = level[(size_t) e];
+            }
+        done += b;
+    }
+#undef HB_CHK
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    cleanup();
+    h->entry = n > 0 ? entry : -1;
+    h->entry_level = n > 0 ? entry_level : -1;
+    // element e holds internal row e alone
+    std::vector<int32_t> erow(alloc, 0), tcount(alloc, 1), itids(alloc * 10, -1);
+    for (int64_t e = 0; e < n; ++e) {
+        erow[(size_t) e] = (int32_t) e;
+        itids[(size_t) e * 10] = (int32_t) e;
+    }
+    auto up = [&](int32_t** d, const int32_t* src, size_t count) -> int {
+        HIPCHK(hipMalloc(d, std::max<size_t>(4, count * sizeof(int32_t))));
+        if (count) HIPCHK(hipMemcpy(*d, src, count * sizeof(int32_t), hipMemcpyHostToDevice));
+        return VSR_OK;
+    };
+    int rc;
+    if ((rc = up(&h->d_elem_row, erow.data(), alloc)) || (rc = up(&h->d_tid_count, tcount.data(), alloc)) ||
+        (rc = up(&h->d_tids, itids.data(), alloc * 10))) {
+        vsr_hnsw_free(h.release());
+        return rc;
+    }
+    c->hnsw_indexes.push_back(h.get());
+    *out = h.release();
+    return VSR_OK;
+}
+
+// what a build left: elements, entry point, its level, the highest level (for reports and tests)
+extern "C" int vsr_hnsw_info(const vsr_hnsw* h, int32_t* n_elem, int32_t* entry, int32_t* entry_level, int32_t* max_level)
+{
+    if (!h) return fail(VSR_ERR_INVALID, "vsr_hnsw_info: index is NULL");
+    if (n_elem) *n_elem = h->n_elem;
+    if (entry) *entry = h->entry;
+    if (entry_level) *entry_level = h->entry_level;
+    if (max_level) *max_level = h->max_level;
     return VSR_OK;
 }
 

@@ -287,6 +287,12 @@ class Corpus:
         row_list = self.ivf_assign(centers, metric)
         return IvfIndex(self, centers, row_list), centers, row_list
 
+    def build_hnsw(self, m=16, ef_construction=64, metric="l2", seed=1):
+        """CREATE INDEX ... USING hnsw on the GPU (vsr_hnsw_build): batched insertion, recall parity with the serial build."""
+        h = C.c_void_p()
+        check(self._lib.vsr_hnsw_build(self._h, int(m), int(ef_construction), _metric(metric), int(seed), C.byref(h)))
+        return HnswIndex(self, h)
+
     def load_hnsw(self, graph):
         """HNSW graph over this corpus; `graph`: dict with m, entry, level, nbr0, tid_count, tids, up_slot, up_nbr,
         max_level (include/vsrbac.h, vsr_hnsw_load: what a dump of pgvector's in-memory build holds)."""
@@ -422,6 +428,9 @@ class HnswIndex:
 
     def __init__(self, corpus, g):
         self.corpus, self._lib = corpus, corpus._lib
+        if isinstance(g, C.c_void_p):                # a handle vsr_hnsw_build returned (Corpus.build_hnsw)
+            self._h = g
+            return
         a = lambda name, dt: np.ascontiguousarray(g[name], dtype=dt)
         level, nbr0, tc, tids = a("level", np.int32), a("nbr0", np.int32), a("tid_count", np.int32), a("tids", np.int64)
         up_slot, up_nbr = a("up_slot", np.int32), a("up_nbr", np.int32)
@@ -442,6 +451,12 @@ class HnswIndex:
                 self.free()
         except Exception:
             pass
+
+    def info(self):
+        """(elements, entry point, its level, highest level) of the graph."""
+        v = [C.c_int32() for _ in range(4)]
+        check(self._lib.vsr_hnsw_info(self._h, *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
 
     def search_device(self, d_queries, nq, k, ef_search, metric, filters, d_block, d_doc, d_rows, d_dist, d_counts,
                       d_visited=None):
