@@ -45,14 +45,14 @@ constexpr int KI_WAVES = 4;
 constexpr int KI_ROWS = 32;                // rows per stage: two list tiles of 16 rows
 constexpr int KI_SLOTS = 4;                // stage ring of a wave: one being multiplied, three in flight
 constexpr int KI_STAGE_U4 = KI_ROWS * 8;   // uint4 per stage (4 KB)
-constexpr int KI_CHUNK = 16;               // stages per mapping chunk (32 list tiles)
+constexpr int KI_CHUNK = 8;                // stages per mapping chunk (16 list tiles)
 constexpr int KI_PARK = 64;                // candidates a wave parks before it reserves room for them
 constexpr int KI_FLUSH_AT = 32;            // ... and the fill level that triggers the reservation
-constexpr int KI_NQ = 64;                  // query columns of a pass
+constexpr int KI_NQ = 128;                 // query columns of a pass, at most (NQG = 8 groups of 16)
 // per wave: [stage ring | |row|^2 ring | thresholds of the current stage | descriptor ring (3 chunks) | permission words ring
 // (2 chunks) | parked candidates {value, row, column} | per-column counts]; per workgroup: [column constants]
 constexpr size_t KI_WAVE_BYTES = (size_t) KI_SLOTS * KI_STAGE_U4 * 16 + KI_SLOTS * KI_ROWS * 4 + KI_ROWS * 4 + 3 * 2 * (2 * KI_CHUNK) * 4 +
-                                 2 * 4 * (2 * KI_CHUNK) * 4 + KI_PARK * 12 + 64 * 4;
+                                 2 * 4 * (2 * KI_CHUNK) * 4 + KI_PARK * 12 + KI_NQ * 4;
 inline size_t i8s_lds_bytes() { return KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16; }
 static_assert(2 * (KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16) <= 160 * 1024, "two workgroups per CU");
 
@@ -96,8 +96,9 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
     uint32_t* pk_v = wring + 2 * 4 * CT;                                        // parked candidates: key high word
     uint32_t* pk_r = pk_v + KI_PARK;                                            //                    row
     uint32_t* pk_c = pk_r + KI_PARK;                                            //                    query column
-    uint32_t* pk_n = pk_c + KI_PARK;                                            // [64] candidates per column
-    float4*   colc = reinterpret_cast<float4*>(smem + KI_WAVES * KI_WAVE_BYTES);   // [64] {c0 bits, |q|^2, slot bits, -}
+    uint32_t* pk_n = pk_c + KI_PARK;                                            // [NC] candidates per column, then their first positions
+    float4*   colc = reinterpret_cast<float4*>(smem + KI_WAVES * KI_WAVE_BYTES);   // [NC] {c0 bits, |q|^2, slot bits, -}
+    constexpr int NC = NQG * 16;                                                // query columns of this instantiation
 
     // ---- this wave's stages: stage i of the wave = list tiles t0 + 2 (wave + 4 i) + {0, 1} of the workgroup's range ----
     const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
     }
 
     // ---- query columns: the thresholds folded into what the integer accumulators start from (vsr_mfmaw.h, ITEST) ----
-    if (tid < KI_NQ) {
+    if (tid < NC) {
         const bool qok = (uint32_t) tid < q_count;
         const uint32_t slot = p.q_slots[grp.q_begin + (qok ? (uint32_t) tid : 0u)];
         const uint64_t tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
@@ -207,21 +208,23 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
     // as the stage loads, so waiting for it drains the three stages in flight: the flush is synchronous but RARE -- a wave
     // parks ~1.5 candidates per stage and flushes when half the parking area is used (every ~20 stages).
     uint32_t n_park = 0;                                                        // wave-uniform
-    const uint32_t my_col_slot = __float_as_uint(colc[lane].z);                 // lane c: query slot of column c
     auto flush = [&]() {
-        pk_n[lane] = 0u;
+#pragma unroll
+        for (int c = 0; c < NC; c += 64) pk_n[c + lane] = 0u;
         wave_fence();
         uint32_t rank_in_col = 0;
         if ((uint32_t) lane < n_park) rank_in_col = atomicAdd(&pk_n[pk_c[lane]], 1u);      // LDS
         wave_fence();
-        const uint32_t mine = pk_n[lane];
-        uint32_t fl_base = 0;
-        if (mine) fl_base = atomicAdd(p.qcnt + my_col_slot, mine);
-        const uint32_t c = (uint32_t) lane < n_park ? pk_c[lane] : 0u;
-        const uint32_t base = (uint32_t) __shfl((int) fl_base, (int) c);
-        const uint32_t slot = (uint32_t) __shfl((int) my_col_slot, (int) c);
+#pragma unroll
+        for (int c = 0; c < NC; c += 64) {                                      // lane: columns lane, lane + 64
+            const uint32_t mine = pk_n[c + lane];
+            if (mine) pk_n[c + lane] = atomicAdd(p.qcnt + __float_as_uint(colc[c + lane].z), mine);
+        }
+        wave_fence();
         if ((uint32_t) lane < n_park) {
-            const uint32_t at = base + rank_in_col;
+            const uint32_t c = pk_c[lane];
+            const uint32_t at = pk_n[c] + rank_in_col;
+            const uint32_t slot = __float_as_uint(colc[c].z);
             const uint32_t row = pk_r[lane];
             if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = ((uint64_t) pk_v[lane] << 32) | (g_rank ? g_rank[row] : row);
         }
@@ -379,11 +382,13 @@ inline hipError_t launch_i8_stream(const ScanParams& p, uint32_t n_blocks, hipSt
     if (p.plane_ho != 2 || p.pstride4 != 8 || p.rw != 16 || p.sample_stride > 1 || p.qmax > (uint32_t) KI_NQ || !p.ones)
         return hipErrorInvalidValue;
     const size_t lds = i8s_lds_bytes();
-    auto kern = i8_stream_kernel<4>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(KI_THREADS), lds, s, p);
-    return hipGetLastError();
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(KI_THREADS), lds, s, p);
+        return hipGetLastError();
+    };
+    return p.qmax > 64 ? launch(i8_stream_kernel<8>) : launch(i8_stream_kernel<4>);
 }
 
 }  // namespace vsr

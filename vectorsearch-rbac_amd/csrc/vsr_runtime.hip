@@ -1226,7 +1226,12 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         k2g = all > 0 && big * 10 >= all * 9;
     }
     if (k2g) wq = (int) GM_QMAX;
-    if (wq > 64 && !k2g) {
+    // int8 planes on K2i: every wave holds the B fragments of the whole pass, and 128 columns fit its registers -- a class seen
+    // by 330 queries is streamed 3 times instead of 6.  The sample launch (K2w's kernel: 64 columns) gets such a pass as two.
+    const bool i8wide = k2w_ok && !k2g && c->d_scr8 && metric == VSR_METRIC_L2 && ctx->int8_this_call && !ctx->no_k2i &&
+                        c->shape.rw == 16 && !ctx->max_qb_set;
+    if (i8wide) wq = 128;
+    if (wq > 64 && !k2g && !i8wide) {
         // long rows: 128-query passes (two groups per wave: a heavier kernel that also fetches the second group's fragments
         // where a pass has none) pay when nearly all (part, query) items sit in parts seen by more than 64 queries --
         // unfiltered batches: 1M x 768 x 1000 queries 9.9 -> 7.9 ms; a role mix (1000 users over 100 roles) would lose:
@@ -1338,8 +1343,9 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
 
     // blocks per pass, then the partial lists of every query as CSR (count, prefix, fill): no per-query vectors
     static thread_local std::vector<uint32_t> loff, lcur, lids, lids_s;
-    static thread_local std::vector<double> gdens;          // per group: permitted fraction of the rows its tiles cover
+    static thread_local std::vector<double> gdens, gdens_s; // per group (sample group): permitted fraction of the rows its tiles cover
     gdens.clear();
+    gdens_s.clear();
     loff.assign((size_t) nq + 1, 0);
     for (auto& p : passes) {
         if (p.n_tiles == 0 || p.rows == 0) continue;       // empty filter part: nothing to scan
@@ -1363,7 +1369,21 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         gs.n_blocks = (uint32_t) std::max<int64_t>(1, nb / seed_div);         // it finishes before the main launch)
         gs.block_begin = plan.n_blocks_s;
         gs.partial_begin = plan.n_partial_s;
+        if (i8wide && p.q_count > 64) {                     // a 128-column pass: two sample groups of at most 64 columns
+            ScanGroup g1 = gs;
+            g1.q_count = (p.q_count / 2 + 15) / 16 * 16;
+            plan.groups_s.push_back(g1);
+            gdens_s.push_back(gdens.back());
+            plan.n_blocks_s += g1.n_blocks;
+            plan.n_partial_s += g1.n_blocks * g1.q_count;
+            gs.q_begin += g1.q_count;
+            gs.q_count = p.q_count - g1.q_count;
+            gs.block_begin = plan.n_blocks_s;
+            gs.partial_begin = plan.n_partial_s;
+            plan.n_partial_s -= gs.n_blocks * p.q_count - gs.n_blocks * gs.q_count;   // (the common accounting below adds the whole pass)
+        }
         plan.groups_s.push_back(gs);
+        gdens_s.push_back(gdens.back());
         for (uint32_t qi = 0; qi < p.q_count; ++qi) loff[plan.q_slots[p.q_off + qi] + 1] += g.n_blocks;
         plan.n_blocks += g.n_blocks;
         plan.n_partial += g.n_blocks * p.q_count;
@@ -1457,7 +1477,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
                 const double waves_per_col = plan.k2g ? 2.0 : ngt == 1 ? 4.0 : ngt == 2 ? 2.0 : 1.0;     // row split (vsr_mfmaw.h)
                 const double entries_per_tile = waves_per_col * (fine ? 4.0 : 1.0);
                 const double rows_per_entry = tile_rows / entries_per_tile;
-                const double p_entry = std::min(1.0, gdens[gi] * rows_per_entry);      // a bitmap may leave an entry without rows
+                const double p_entry = std::min(1.0, gdens_s[gi] * rows_per_entry);    // a bitmap may leave an entry without rows
                 for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * entries_per_tile * p_entry;
             }
             for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
@@ -1779,7 +1799,8 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
             sp.epi = rows_per_query > 0 && 1024.0 * admitted / rows_per_query <= 4.0 ? 1u : 0u;
         }
         if (ctx->force_epi >= 0) sp.epi = (uint32_t) ctx->force_epi;
-        sp.k2i = plan.int8 && !plan.k2g && sp.epi == 1 && !ctx->no_k2i && sp.rw == 16 && sp.qmax <= 64 ? 1u : 0u;
+        if (plan.int8 && plan.qmax > 64) sp.epi = 1u;       // 128-column passes exist on K2i only (its parking area takes bursts)
+        sp.k2i = plan.int8 && !plan.k2g && sp.epi == 1 && !ctx->no_k2i && sp.rw == 16 && sp.qmax <= 128 ? 1u : 0u;
         ctx->last_k2i = sp.k2i != 0;
         sp.tau_init = ctx->d_tau.as<uint64_t>();
         sp.qcand = ctx->d_cand.as<uint64_t>();
