@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r2", "traffic.json"),
                     help="PMC-derived HBM bytes per launch (tools/pmc_traffic.py) for roofline.traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-line", action="store_true", help="skip the VSR_NO_INT8 sibling record of the headline leg")
     ap.add_argument("--sharding", default="auto", choices=["auto", "placement", "rows"],
                     help="N > 1: 'placement' = whole role partitions on GPUs, a query touches ONE GPU, no exchange (SURVEY 8e-ii); "
                          "'rows' = contiguous row ranges, every query on every GPU, all-gather + merge (SURVEY 8e-i); auto = placement")
@@ -273,6 +274,38 @@ def hnsw_legs(args, torch, ctx, orc, box, qvec, k, dev):
                        "elements x d x 4; SURVEY 8d's gather figure) over the launch time -- a graph walk is a chain of "
                        "dependent gathers, latency- not bandwidth-bound, so the fraction is small by nature"}
         gidx.free()
+        # CREATE INDEX on the GPU (vsr_hnsw_build: batched insertion) over the same rows: build time beside the CPU port's, and
+        # the same ef_search sweep on the graph it leaves (another graph than the serial build's: recall is the parity measure)
+        try:
+            tb = time.perf_counter()
+            bidx = c2.build_hnsw(16, 64, "l2", seed=args.seed)
+            gb_s = time.perf_counter() - tb
+            bsweep = []
+            for pt in sweep:
+                ef = pt["ef_search"]
+                call = lambda: bidx.search_device(ptr(d_q), nq, k, ef, "l2", None, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist),
+                                                  ptr(o_cnt), ptr(o_vis))
+                call()
+                ctx.synchronize()
+                th = time.perf_counter()
+                for _ in range(3):
+                    call()
+                ctx.synchronize()
+                gs = (time.perf_counter() - th) / 3
+                rows_g, cnt_g = o_row.cpu().numpy(), o_cnt.cpu().numpy()
+                if (cnt_g < 0).any():
+                    res, _ = bidx.search(gq, k, ef)
+                    rows_g, cnt_g = res.rows, res.counts
+                bsweep.append({"ef_search": ef, "qps": round(nq / gs, 1),
+                               "recall_at_k": round(recall_of([rows_g[i][:int(cnt_g[i])] for i in range(len(hq))]), 4),
+                               "recall_of_cpu_built_graph": pt["recall_at_k"]})
+            gpu["gpu_built_graph"] = {"build_s": round(gb_s, 2), "cpu_port_build_s": cpu["build_s"],
+                                      "build_speedup": round(cpu["build_s"] / max(gb_s, 1e-9), 1), "sweep": bsweep,
+                                      "note": "vsr_hnsw_build: batches of at most 1/8 of the graph, one wave per new element; same m, "
+                                              "ef_construction and level stream as the CPU port"}
+            bidx.free()
+        except Exception as exc:
+            gpu["gpu_built_graph"] = {"error": repr(exc)}
         c2.free()
     except Exception as exc:
         gpu = {"error": repr(exc)}
@@ -621,7 +654,8 @@ def main():
     lo, hi = shard_bounds(n, world, rank, align=100)  # keep documents (100 rows) whole per shard
     t0 = time.time()
     x, blk, doc = sift_like_corpus(hi - lo, dim, seed=args.seed, start=lo)
-    rbac = tree_rbac(num_users=1000, num_roles=100, num_docs=n // 100, seed=args.seed)
+    rbac = tree_rbac(num_users=1000, num_roles=100, num_docs=n // 100, seed=args.seed,
+                     clustered=os.environ.get("VSR_BENCH_CLUSTERED") == "1")      # (development: what contiguous classes would buy)
     nb = max(1, min(args.batches, args.steps + args.warmup))
     batches = []                                      # fresh (rows, users) per step from the seeded stream, cycled
     for b in range(nb):
@@ -966,6 +1000,29 @@ def main():
                                 f"the distance loop (BASELINE config 4's mode)" if leg == "postfilter" else leg)
     if sustained:
         out["sustained"] = sustained
+
+    # ---- sibling line (N = 1): the same headline leg with the int8 planes switched off (VSR_NO_INT8): hi-only bf16 planes,
+    # 260 bytes per row instead of 132, fp32 accumulation, same exact results ----
+    if world == 1 and sim_world <= 1 and not args.no_bf16_line:
+        os.environ["VSR_NO_INT8"] = "1"
+        try:
+            c_bf = ctx.load_corpus(x, blk, doc, row_offset=lo)
+        finally:
+            del os.environ["VSR_NO_INT8"]
+        c_bf.load_rbac(rbac.user_roles, rbac.permissions)
+        filt_bf = {legs[0]: [c_bf.pack_filters([c_bf.filter_for_user(int(u), MODES[legs[0]]) for u in quser]) for _, quser in batches]}
+        saved = (corpus, filt)
+        corpus, filt = c_bf, filt_bf                      # (timed_leg / alone_stats / leg_record read these names)
+        try:
+            rb = timed_leg(legs[0], args.steps, args.warmup)
+            rb["alone"] = alone_stats(legs[0])
+            rec_bf = leg_record(legs[0], rb)
+            rec_bf["roofline"]["traffic"] = None          # (the PMC file holds the int8 launch's bytes)
+            rec_bf["dtype"] = "bf16 planes -> f32 accumulate (screen; exact for these integer rows), f32 exact re-rank"
+            out["bf16_planes"] = rec_bf
+        finally:
+            corpus, filt = saved
+            c_bf.free()
 
     d_keys, d_blk, d_doc, d_dist = d_views[0]         # slot 0 / session 0 from here on (everything above has drained)
     d_row, d_cnt = d_rows[0], d_cnts[0]

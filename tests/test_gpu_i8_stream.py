@@ -55,7 +55,8 @@ def test_k2i_matches_oracle_and_k2w(oracle, monkeypatch, mode):
     q[:, :5] = rng.integers(0, 256, (nq, 5)).astype(np.float32)
     masks = [None if r < 0 else row_masks[r] for r in role_of]
     results = {}
-    for label, env in (("k2i", {"VSR_FORCE_EPI": "1", "VSR_K2I": "1"}), ("k2w", {"VSR_FORCE_EPI": "1"})):
+    for label, env in (("k2i", {"VSR_FORCE_EPI": "1", "VSR_K2I": "1"}), ("k2i_wide", {"VSR_FORCE_EPI": "1", "VSR_K2I": "1", "VSR_K2I_WIDE": "1"}),
+                       ("k2w", {"VSR_FORCE_EPI": "1"})):
         ctx = _ctx(monkeypatch, **env)
         corpus = ctx.load_corpus(x, blk, doc)
         fmode = vsrbac.RANGES if mode == "ranges" else vsrbac.BITMAP
@@ -63,17 +64,18 @@ def test_k2i_matches_oracle_and_k2w(oracle, monkeypatch, mode):
         filters = [None if r < 0 else role_filters[r] for r in role_of]
         res = corpus.search(q, k, "l2", filters)
         name = ctx.last_scan_kernel()
-        assert ("K2i" in name) == (label == "k2i"), name
+        assert ("K2i" in name) == label.startswith("k2i"), name
         assert "int8" in name, name
         results[label] = res
         if label == "k2i":
             _check(oracle, res, list(range(0, nq, 5)) + [int(i) for i in np.flatnonzero(role_of == 2)], x, q, k, doc, blk, masks)
         corpus.free()
         ctx.close()
-    a, b = results["k2i"], results["k2w"]
-    np.testing.assert_array_equal(a.counts, b.counts)
-    np.testing.assert_array_equal(a.rows, b.rows)
-    np.testing.assert_array_equal(a.dist, b.dist)
+    for other in ("k2i_wide", "k2w"):                                  # 128-column passes (8 groups per wave); K2w's tiles
+        a, b = results["k2i"], results[other]
+        np.testing.assert_array_equal(a.counts, b.counts)
+        np.testing.assert_array_equal(a.rows, b.rows)
+        np.testing.assert_array_equal(a.dist, b.dist)
 
 
 def test_k2i_short_streams_and_device_api(oracle, monkeypatch):

@@ -182,6 +182,7 @@ struct vsr_ctx {
     bool no_k2i = true;            // VSR_K2I=1: the int8 main launch as K2i's per-wave streams instead of K2w's workgroup tiles (A/B;
                                    // measured on the headline step: K2w 0.342 ms, K2i 0.366 ms -- K2w stays the default)
     bool last_k2i = false;         // the last main launch was eligible for K2i
+    bool k2i_wide = false;         // VSR_K2I_WIDE=1 (with VSR_K2I=1): 128-column passes on K2i
     int  force_epi = -1;           // VSR_FORCE_EPI=0|1: the main launch's survivor handling regardless of the estimate (tests)
     int  screen_level = 2;         // search_impl -> make_plan: 2 = every screening tier, 1 = no coarse tier (K2g), 0 = exact only
     bool last_coarse = false;      // the last search screened on the coarse planes: its flagged queries go to the fine tier first
@@ -331,6 +332,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_NO_GEMM"))) ctx->no_gemm = atoi(env) != 0;
     if ((env = getenv("VSR_K2I"))) ctx->no_k2i = atoi(env) == 0;
     if ((env = getenv("VSR_FORCE_EPI"))) ctx->force_epi = atoi(env) != 0;
+    if ((env = getenv("VSR_K2I_WIDE"))) ctx->k2i_wide = atoi(env) != 0;
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
@@ -1228,8 +1230,10 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
     if (k2g) wq = (int) GM_QMAX;
     // int8 planes on K2i: every wave holds the B fragments of the whole pass, and 128 columns fit its registers -- a class seen
     // by 330 queries is streamed 3 times instead of 6.  The sample launch (K2w's kernel: 64 columns) gets such a pass as two.
+    // (measured on the headline step: 12 % fewer pass rows, but the 8-group instantiation -- 223 VGPRs, its candidate masks
+    // spilled to lanes -- is slower per row: 0.43 ms against 0.357 ms for 64-column passes.  Opt-in: VSR_K2I_WIDE=1.)
     const bool i8wide = k2w_ok && !k2g && c->d_scr8 && metric == VSR_METRIC_L2 && ctx->int8_this_call && !ctx->no_k2i &&
-                        c->shape.rw == 16 && !ctx->max_qb_set;
+                        ctx->k2i_wide && c->shape.rw == 16 && !ctx->max_qb_set;
     if (i8wide) wq = 128;
     if (wq > 64 && !k2g && !i8wide) {
         // long rows: 128-query passes (two groups per wave: a heavier kernel that also fetches the second group's fragments

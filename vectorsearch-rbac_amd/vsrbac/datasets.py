@@ -116,7 +116,8 @@ def _finish(user_roles, role_docs, num_users, parent=None):
                 parent or {}, m)
 
 
-def tree_rbac(num_users=1000, num_roles=100, num_docs=10_000, h=4, b0=3, b1=4, seed=20251121):
+def tree_rbac(num_users=1000, num_roles=100, num_docs=10_000, h=4, b0=3, b1=4, seed=20251121, clustered=False):
+    """clustered (development, not the reference's generator): every role's own documents are one run of consecutive ids."""
     rng = np.random.default_rng([int(seed), 11])
     remaining = list(range(1, num_roles + 1))
     children = {0: []}
@@ -139,6 +140,8 @@ def tree_rbac(num_users=1000, num_roles=100, num_docs=10_000, h=4, b0=3, b1=4, s
     add_children(0, 0)
     n_sets = len(order)
     docs = rng.permutation(np.arange(1, num_docs + 1, dtype=np.int32))
+    if clustered:
+        docs = np.arange(1, num_docs + 1, dtype=np.int32)
     size = num_docs // n_sets
     own = {}
     for i, role in enumerate(order):
