@@ -705,6 +705,65 @@ def test_one_query_per_call_is_one_launch_and_exact(ctx, oracle):
     corpus.free()
 
 
+def test_one_query_per_call_on_int8_planes(ctx, oracle):
+    """nq == 1 over a SIFT-like corpus: the fused launch reads the int8 planes (scan8_fused_kernel: a quarter of the bytes
+    per row) and returns the bytes the fp32 kernel returns.  Host queries are checked by the library; device queries
+    only under the u8 hint, verified in the kernel: a query that is not integer-valued in 0..255 is FLAGGED (negative
+    count) and the exact variant re-runs it on the fp32 rows."""
+    import torch
+    import vsrbac
+    rng = np.random.default_rng(909)
+    for n, dim in ((200_000, 128), (30_000, 96)):
+        x = sift_like(rng, n, dim)
+        blk, doc = _ids(n, 37)                                          # ragged tiles: 16 + 16 + 5
+        corpus = ctx.load_corpus(x, blk, doc)
+        mask = (rng.random(int(doc.max()) + 1) < 0.4)[doc].astype(np.uint8)
+        for mode in (vsrbac.RANGES, vsrbac.BITMAP, None):
+            f = None if mode is None else corpus.filter_from_bytemask(mask, mode)
+            for k in (1, 10, 100):
+                q = x[rng.integers(0, n)].copy()
+                q[:4] = rng.integers(0, 256, 4)
+                res = corpus.search(q[None, :], k, "l2", None if f is None else [f])
+                assert "scan8" in ctx.last_scan_kernel(), ctx.last_scan_kernel()
+                _expect_exact(oracle, res, 0, "l2", x, q, k, doc, blk, None if f is None else mask)
+        q = x[7].copy()
+        res = corpus.search(q[None, :], 10, "ip")
+        assert "scan8" not in ctx.last_scan_kernel()                   # an L2 path only
+        q[3] = 0.5
+        res = corpus.search(q[None, :], 10, "l2")                       # not u8-exact: the fp32 rows
+        assert "scan8" not in ctx.last_scan_kernel()
+        _expect_exact(oracle, res, 0, "l2", x, q, 10, doc, blk)
+        # device-resident queries
+        dev = torch.device("cuda", 0)
+        k = 20
+        outs = (torch.empty((1, k), dtype=torch.int64, device=dev), torch.empty((1, k), dtype=torch.int32, device=dev),
+                torch.empty((1, k), dtype=torch.int64, device=dev), torch.empty((1, k), dtype=torch.float32, device=dev),
+                torch.empty((1,), dtype=torch.int32, device=dev))
+        ptrs = tuple(t.data_ptr() for t in outs)
+        good = x[11].copy()
+        d_good, d_bad = torch.from_numpy(good[None, :].copy()).to(dev), torch.from_numpy(q[None, :].copy()).to(dev)
+        corpus.search_device(d_good.data_ptr(), 1, k, "l2", None, *ptrs)
+        ctx.synchronize()
+        assert "scan8" not in ctx.last_scan_kernel()                   # nothing is assumed without the hint
+        ctx.set_query_hint(True)
+        corpus.search_device(d_good.data_ptr(), 1, k, "l2", None, *ptrs)
+        ctx.synchronize()
+        assert "scan8" in ctx.last_scan_kernel() and int(outs[4].cpu()[0]) == k
+        got = SimpleNamespace(block_ids=outs[0].cpu().numpy(), doc_ids=outs[1].cpu().numpy(), rows=outs[2].cpu().numpy(),
+                              dist=outs[3].cpu().numpy(), counts=outs[4].cpu().numpy())
+        _expect_exact(oracle, got, 0, "l2", x, good, k, doc, blk)
+        corpus.search_device(d_bad.data_ptr(), 1, k, "l2", None, *ptrs)  # the promise is broken
+        _, flags = ctx.screening_check(1)
+        assert flags[0] and int(outs[4].cpu()[0]) < 0
+        ctx.set_query_hint(True)
+        assert corpus.search_device_exact(d_bad.data_ptr(), 1, k, "l2", None, *ptrs) == 1
+        got = SimpleNamespace(block_ids=outs[0].cpu().numpy(), doc_ids=outs[1].cpu().numpy(), rows=outs[2].cpu().numpy(),
+                              dist=outs[3].cpu().numpy(), counts=outs[4].cpu().numpy())
+        _expect_exact(oracle, got, 0, "l2", x, q, k, doc, blk)
+        ctx.set_query_hint(False)
+        corpus.free()
+
+
 def test_int8_planes_for_sift_like_queries(ctx, oracle):
     """A corpus of integers 0..255 (d <= 128) keeps int8 planes; L2 searches whose queries are such integers screen on
     them (v_mfma_i32_16x16x64_i8, exact).  Host queries are checked by the library; device-resident queries only under

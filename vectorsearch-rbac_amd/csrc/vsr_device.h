@@ -75,6 +75,7 @@ struct FusedTail {
     uint64_t*       out_keys;      // may be nullptr
     int32_t*        out_count;
     int32_t*        out_flag;      // the call's flag word (the exact path never flags: cleared)
+    int32_t*        flag_total;    // the session's count of flagged queries (scan8: a query that broke the u8 promise); may be null
     uint32_t        row_offset;
     int             metric;
 };
@@ -215,6 +216,8 @@ inline size_t scan_lds_bytes(uint32_t qmax, uint32_t cap, uint32_t stride4)
     return (size_t) qmax * ((size_t) cap * 8 + 16 + (size_t) stride4 * 16 + 4) + 16;
 }
 hipError_t launch_scan(const ScanParams& p, int metric, int dim, int qi, uint32_t n_blocks, hipStream_t s);
+// one query per call over the int8 planes (vsr_scan8.h): K1's top-k and in-kernel merge, a quarter of the bytes per row
+hipError_t launch_scan8_fused(const ScanParams& p, uint32_t dim, uint32_t* q8_bad_host, uint32_t n_blocks, hipStream_t s);
 // K1m (vsr_mq.h): shared-pass kernel for 2..16 queries per pass; needs dim >= 61 (>= 16 float4 per row)
 bool mq_supported(int dim);
 int  mq_qmax(int dim);

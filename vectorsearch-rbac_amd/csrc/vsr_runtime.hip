@@ -182,6 +182,7 @@ struct vsr_ctx {
     bool no_k2i = true;            // VSR_K2I=1: the int8 main launch as K2i's per-wave streams instead of K2w's workgroup tiles (A/B;
                                    // measured on the headline step: K2w 0.342 ms, K2i 0.366 ms -- K2w stays the default)
     bool last_k2i = false;         // the last main launch was eligible for K2i
+    bool no_scan8 = false;         // VSR_NO_SCAN8=1: one-query calls on the fp32 rows even when the int8 planes apply (A/B)
     bool k2i_wide = false;         // VSR_K2I_WIDE=1 (with VSR_K2I=1): 128-column passes on K2i
     int  force_epi = -1;           // VSR_FORCE_EPI=0|1: the main launch's survivor handling regardless of the estimate (tests)
     int  screen_level = 2;         // search_impl -> make_plan: 2 = every screening tier, 1 = no coarse tier (K2g), 0 = exact only
@@ -333,6 +334,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_K2I"))) ctx->no_k2i = atoi(env) == 0;
     if ((env = getenv("VSR_FORCE_EPI"))) ctx->force_epi = atoi(env) != 0;
     if ((env = getenv("VSR_K2I_WIDE"))) ctx->k2i_wide = atoi(env) != 0;
+    if ((env = getenv("VSR_NO_SCAN8"))) ctx->no_scan8 = atoi(env) != 0;
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
@@ -2006,7 +2008,23 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
                 e1 = take_event(ctx);
                 HIPCHK(hipEventRecord(e0, ctx->stream));
             }
-            HIPCHK(launch_scan(sp, metric, c->dim, 1, g.n_blocks, ctx->stream));
+            // SIFT-like corpus and query (u8-exact, L2): the same launch over the int8 planes -- a quarter of the bytes per
+            // row, identical distances (vsr_scan.h, scan8_fused_kernel)
+            const bool scan8 = c->d_scr8 && !c->base && metric == VSR_METRIC_L2 && ctx->int8_this_call && c->shape.rw == 16 &&
+                               !ctx->no_scan8;
+            if (scan8) {
+                if (!ctx->h_q8.p) {
+                    if ((rc = ctx->h_q8.reserve(64))) return rc;
+                    memset(ctx->h_q8.p, 0, 64);
+                }
+                sp.scr = c->d_scr8;
+                sp.norm2 = c->d_norm2_8;
+                sp.pstride4 = 8;
+                sp.plane_ho = 2u;
+                sp.fused.flag_total = ctx->d_flag_total;
+                HIPCHK(launch_scan8_fused(sp, (uint32_t) dim, reinterpret_cast<uint32_t*>(ctx->h_q8.dp), g.n_blocks, ctx->stream));
+            } else
+                HIPCHK(launch_scan(sp, metric, c->dim, 1, g.n_blocks, ctx->stream));
             if (!d_queries) {
                 HIPCHK(hipEventRecord(ctx->desc_done, ctx->stream));
                 ctx->desc_pending = true;
@@ -2015,7 +2033,8 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
                 HIPCHK(hipEventRecord(e1, ctx->stream));
                 ctx->pending.push_back({e0, e1, 0});
             }
-            ctx->last_kernel = scan_kernel_name(plan, c, metric) + " + in-kernel merge";
+            ctx->last_kernel = scan8 ? std::string("vsr::scan8_fused_kernel (K1 on the int8 planes) + in-kernel merge")
+                                     : scan_kernel_name(plan, c, metric) + " + in-kernel merge";
             ctx->stats.scan_bytes[0] += plan.scan_bytes;
             ctx->stats.scan_rows[0] += plan.scan_rows;
             ctx->stats.scan_pairs[0] += plan.scan_pairs;

@@ -245,8 +245,10 @@ __device__ __forceinline__ uint32_t fused_block_select(const uint64_t* src, uint
     return cnt[1];
 }
 
+// bad: the query broke a promise the kernel relied on (scan8: not integer-valued in 0..255): the result is written but FLAGGED
+// (negative count, flag word set), like a query the screening could not prove; the caller re-runs it on the exact path
 __device__ __forceinline__ void fused_tail(const ScanParams& p, const ScanGroup& grp, uint32_t local_block, uint64_t* keys,
-                                        int tid)
+                                        int tid, bool bad = false)
 {
     __shared__ uint32_t s_last;
     const FusedTail& f = p.fused;
@@ -305,8 +307,9 @@ __device__ __forceinline__ void fused_tail(const ScanParams& p, const ScanGroup&
         }
     }
     if (tid == 0) {
-        f.out_count[0] = (int32_t) m;
-        f.out_flag[0] = 0;
+        f.out_count[0] = bad ? -1 - (int32_t) m : (int32_t) m;
+        f.out_flag[0] = bad ? 1 : 0;
+        if (bad && f.flag_total) atomicAdd(f.flag_total, 1);
     }
     for (uint32_t i = tid; i < 1 + n_g; i += SCAN_THREADS) f.done[i] = 0;     // every other workgroup is past its counter
 }

@@ -1,5 +1,6 @@
 // vsr_scan_l2.hip — instantiates the K1 scan kernels for one metric (one TU per metric: parallel builds).
 #include "vsr_scan.h"
+#include "vsr_scan8.h"
 #include "vsr_mq.h"
 #include "vsr_mfma.h"
 

@@ -60,15 +60,33 @@ def sift_like_rows(start, stop, dim=128, seed=20251121, workers=None):
     return out
 
 
-def sift_like_rows_at(indices, dim=128, seed=20251121):
-    """The SIFT-like rows at arbitrary row indices (query vectors are sampled corpus rows)."""
+def sift_like_rows_at(indices, dim=128, seed=20251121, workers=None):
+    """The SIFT-like rows at arbitrary row indices (query vectors are sampled corpus rows; a rank of the placement mode
+    holds the rows of its roles' documents).  Chunks are generated on a small thread pool, each only as far as needed."""
     indices = np.asarray(indices, dtype=np.int64)
     out = np.empty((indices.size, dim), dtype=np.float32)
-    for c in np.unique(indices // CHUNK):
-        sel = np.flatnonzero(indices // CHUNK == c)
-        local = indices[sel] - c * CHUNK
-        part = _sift_chunk(seed, int(c), int(local.max()) + 1, dim)
-        out[sel] = part[local]
+    if indices.size == 0:
+        return out
+    order = np.argsort(indices, kind="stable")
+    sorted_idx = indices[order]
+    chunk_of = sorted_idx // CHUNK
+    cuts = np.flatnonzero(np.diff(chunk_of)) + 1
+    starts = np.concatenate([[0], cuts])
+    stops = np.concatenate([cuts, [sorted_idx.size]])
+
+    def run(j):
+        a, b = int(starts[j]), int(stops[j])
+        c = int(chunk_of[a])
+        local = sorted_idx[a:b] - c * CHUNK
+        part = _sift_chunk(seed, c, int(local[-1]) + 1, dim)
+        out[order[a:b]] = part[local]
+
+    if len(starts) == 1:
+        run(0)
+    else:
+        workers = workers or max(1, min(8, (os.cpu_count() or 2) // 2))
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(run, range(len(starts))))
     return out
 
 
