@@ -29,6 +29,7 @@ seed = 20251121
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 ctx = vsrbac.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+ctx.set_query_hint(True)          # the queries are corpus rows: integers 0..255 (bench.py gives the same promise)
 x, blk, doc = sift_like_corpus(a.rows, 128, seed=seed)
 rbac = tree_rbac(num_users=1000, num_roles=100, num_docs=a.rows // 100, seed=seed)
 c = ctx.load_corpus(x, blk, doc); c.load_rbac(rbac.user_roles, rbac.permissions)

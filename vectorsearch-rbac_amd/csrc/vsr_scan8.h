@@ -75,7 +75,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan8_fused_kernel(const Scan
         tr.x[0] = tr.x[1] = make_uint4(0u, 0u, 0u, 0u);
         tr.rn[0] = tr.rn[1] = 0.0f;
         if (t >= t1) return;
-        const uint2 tl = load_tile(g_tiles, t);
+        uint2 tl;
+        if (g_tiles) tl = load_tile(g_tiles, t);
+        else {                                               // no filter: the identity tiling of the corpus
+            tl.x = t * RW;
+            tl.y = p.n_rows - tl.x < (uint32_t) RW ? p.n_rows - tl.x : (uint32_t) RW;
+        }
         uint32_t mask = tl.y >= 16u ? 0xFFFFu : (1u << tl.y) - 1u;
         if (g_bitmap) mask &= (uint32_t) bitmap_window(g_bitmap, tl.x);
         tr.start = tl.x;
