@@ -103,8 +103,8 @@ def kernel_layout(kernel, dim):
     if "K2g" in kernel:                  # coarse bf16 planes (hi only), rows padded to whole 64-element K-steps; one product
         d_pad = -(-dim // 64) * 64
         return d_pad * 2 + 4, 2 * d_pad, MFMA_BF16_PEAK_TF
-    if "K2w" in kernel:
-        if "PL=int8" in kernel:          # int8 planes (x - 128), 128 elements per row; one product, exact
+    if "K2w" in kernel or "K2i" in kernel:
+        if "int8" in kernel:             # int8 planes (x - 128), 128 elements per row; one product, exact
             d_pad = -(-dim // 128) * 128
             return d_pad + 4, 2 * d_pad, MFMA_I8_PEAK_TOPS
         if "HO=true" in kernel:          # hi-only bf16 planes, rows padded to whole 128-element stages; products xh*qh + xh*qm
@@ -599,7 +599,7 @@ def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim
             "value": round(nq * args.steps / head["dt"], 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(head["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": ("int8 planes -> i32 (exact: bit-identical to the fp32 distances of vector.c)" if "PL=int8" in head["kernel"]
+            "dtype": ("int8 planes -> i32 (exact: bit-identical to the fp32 distances of vector.c)" if "int8" in head["kernel"]
                       else "bf16 planes -> f32 (screen), f32 exact re-rank" if "K2" in head["kernel"] else "f32"),
             "data": "synthetic",
             "config": {"workload": f"SIFT10M-like {n}x{dim} fp32 L2 k={k}, tree RBAC 1000 users/100 roles, role-partition "
@@ -1014,7 +1014,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
-        "dtype": ("int8 planes -> i32 (exact: bit-identical to the fp32 distances of vector.c)" if "PL=int8" in results[legs[0]]["kernel"]
+        "dtype": ("int8 planes -> i32 (exact: bit-identical to the fp32 distances of vector.c)" if "int8" in results[legs[0]]["kernel"]
                   else "bf16 planes -> f32 (screen), f32 exact re-rank" if "K2" in results[legs[0]]["kernel"] else "f32"),
         "data": "synthetic",
         "config": {"workload": f"SIFT10M-like {n}x{dim} fp32 L2 k={k}, tree RBAC 1000 users/100 roles, "
