@@ -132,6 +132,7 @@ class PlacedDeployment:
         heat = partition_heat(self.comb_role_partitions, loads, role_weights, rows.shape[1])
         self.placement, self.gpu_heat, self.gpu_rows = place_partitions(loads, heat, self.n_gpus, replicate_above)
         self.deployments = []
+        self._pool = None                                 # host threads, one per GPU a query touches (created on first use)
         for g, ctx in enumerate(contexts):
             mine = [p for p, gs in self.placement.items() if g in gs]
             docs = np.unique(np.concatenate([self.partition_docs[p] for p in mine])) if mine else np.zeros(0, np.int32)
@@ -147,6 +148,9 @@ class PlacedDeployment:
             self.deployments.append(dep)
 
     def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         for d in self.deployments:
             if d is not None:
                 d.close()
@@ -168,13 +172,26 @@ class PlacedDeployment:
         plan = self.route(comb)
         if not plan:
             return [], 0.0
-        all_rows, secs = [], 0.0
-        for g, pids in plan.items():
+        def on_gpu(item):
+            g, pids = item
             dep = self.deployments[g]
             filters = [dep._partition_filter(p, user_id) for p in pids]
             qs = np.repeat(q[None, :], len(pids), axis=0)
             res, t = dep._timed(statistics_type, lambda: dep.corpus.search(qs, topk, dep.metric, filters))
-            secs = max(secs, t)                               # the GPUs work side by side
+            rows = []
             for i in range(len(pids)):
-                all_rows.extend(dep._rows(res, i))
-        return merge_results(all_rows, topk), secs
+                rows.extend(dep._rows(res, i))
+            return rows, t
+
+        # the GPUs of a query work side by side: one host thread per GPU (the C call releases the GIL), so the slowest GPU's
+        # time is the query's time -- issued one after another (as this loop once did) the times would add up
+        items = list(plan.items())
+        if len(items) == 1:
+            parts = [on_gpu(items[0])]
+        else:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=len(self.deployments))
+            parts = list(self._pool.map(on_gpu, items))
+        all_rows = [r for rows, _ in parts for r in rows]
+        return merge_results(all_rows, topk), max(t for _, t in parts)
