@@ -33,17 +33,23 @@ def _kernel(lines, mangled):
 
 
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("nqg", [4, 8])
-def test_k2i_stage_loop_has_only_counted_waits(tmp_path, nqg):
+@pytest.mark.parametrize("nqg,sample", [(4, False), (8, False), (4, True)])
+def test_k2i_stage_loop_has_only_counted_waits(tmp_path, nqg, sample):
+    flag = "true" if sample else "false"
     lines = _asm(tmp_path, '#include <hip/hip_runtime.h>\n#include "vsr_i8s.h"\n'
-                           f'namespace vsr {{ template __global__ void i8_stream_kernel<{nqg}>(const ScanParams); }}\n')
-    k = _kernel(lines, f"_ZN3vsr16i8_stream_kernelILi{nqg}EEEvNS_10ScanParamsE")
+                           f'namespace vsr {{ template __global__ void i8_stream_kernel<{nqg}, {flag}>(const ScanParams); }}\n')
+    k = _kernel(lines, f"_ZN3vsr16i8_stream_kernelILi{nqg}ELb{int(sample)}EEEvNS_10ScanParamsE")
     mfma = [i for i, l in enumerate(k) if "v_mfma_i32_16x16x64_i8" in l]
     assert len(mfma) == 4 * nqg, len(mfma)                               # 2 row blocks x NQG groups x 2 k-steps, no unrolled copies
     head = max(i for i, l in enumerate(k) if "Loop Header" in l and "Depth=1" in l and i < mfma[0])
-    # the common path of a stage: from the loop header through the MFMAs and the candidate compares up to the scalar test that
-    # skips the (rare) candidate handling
-    tail = next(i for i in range(mfma[-1], len(k)) if "s_cmp_eq_u64" in k[i])
+    if sample:
+        # the sample variant's stage has no rare branch: the whole loop body is the common path
+        label = k[head].split(":")[0]
+        tail = max(i for i, l in enumerate(k) if "Header=" + label.lstrip(".L") in l)      # the last block of the loop
+    else:
+        # the common path of a stage: from the loop header through the MFMAs and the candidate compares up to the scalar test
+        # that skips the (rare) candidate handling
+        tail = next(i for i in range(mfma[-1], len(k)) if "s_cmp_eq_u64" in k[i])
     waits = [l.strip() for l in k[head:tail] if "s_waitcnt" in l and "vmcnt" in l]
     assert waits, "the counted waits are gone"
     assert all(re.fullmatch(r"s_waitcnt vmcnt\((10|12|16)\)", w) for w in waits), waits

@@ -120,7 +120,7 @@ struct ScanParams {
     const uint64_t*  ones;         // one all-ones 64-bit word (the "bitmap" of passes without a permission bitmap)
     uint32_t*        err;          // bounds-guard word: 1 = row index out of range, 2 = candidate buffer overflow, 4 = tile index
     uint32_t         epi;          // K2w main launch, L2: 1 = few survivors expected per wave-tile (mask epilogue), 0 = rounds
-    uint32_t         k2i;          // int8 planes, epi == 1: the main launch may run as per-wave streams (K2i, vsr_i8s.h)
+    uint32_t         k2i;          // int8 planes: bit 0 = the main launch (epi == 1), bit 1 = the sample launch runs as per-wave streams (K2i, vsr_i8s.h)
     FusedTail        fused;        // K1, nq == 1 only (enable = 0 otherwise)
 };
 

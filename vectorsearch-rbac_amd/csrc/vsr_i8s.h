@@ -56,7 +56,11 @@ constexpr size_t KI_WAVE_BYTES = (size_t) KI_SLOTS * KI_STAGE_U4 * 16 + KI_SLOTS
 inline size_t i8s_lds_bytes() { return KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16; }
 static_assert(2 * (KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16) <= 160 * 1024, "two workgroups per CU");
 
-template <int NQG>
+// SAMPLE: the threshold-seeding pass (ScanParams::sample_stride > 1): every ss-th stage of the workgroup's range, no
+// thresholds; every lane keeps the smallest (value, row) of each of its query columns over the wave's whole stream and
+// appends them to the queries' sample buffers when the stream ends (4 entries per column and wave: a subset of the
+// sampled values, which can only loosen the seed -- vsr_mfmaw.h).  The values are compared as integers (|x'|^2 - 2 x'.q').
+template <int NQG, bool SAMPLE = false>
 __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -103,13 +107,14 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
     // ---- this wave's stages: stage i of the wave = list tiles t0 + 2 (wave + 4 i) + {0, 1} of the workgroup's range ----
     const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
     const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
-    const uint32_t n_st = (t1 - t0 + 1u) >> 1;
+    const uint32_t ss = SAMPLE ? p.sample_stride : 1u;                          // sample pass: every ss-th stage
+    const uint32_t n_st = (((t1 - t0 + 1u) >> 1) + ss - 1u) / ss;
     const uint32_t n_w = n_st > (uint32_t) wave ? (n_st - (uint32_t) wave + 3u) >> 2 : 0u;
     const uint32_t tile_last = grp.n_tiles - 1u;
     const uint32_t last_row = p.n_rows - 1u;
 
     // list tile J (0 .. ) of mapping chunk c, as this wave numbers them: stage KI_CHUNK c + (J >> 1), half J & 1
-    auto tile_of = [&](uint32_t c, uint32_t J) -> uint32_t { return t0 + 2u * ((uint32_t) wave + 4u * (c * KI_CHUNK + (J >> 1))) + (J & 1u); };
+    auto tile_of = [&](uint32_t c, uint32_t J) -> uint32_t { return t0 + 2u * ss * ((uint32_t) wave + 4u * (c * KI_CHUNK + (J >> 1))) + (J & 1u); };
     auto fetch_desc = [&](uint32_t c) {                                        // chunk c's descriptors -> LDS (lane L < CT: tile L)
         if ((uint32_t) lane >= CT) return;
         const uint32_t t = tile_of(c, (uint32_t) lane);
@@ -129,11 +134,11 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
     if (tid < NC) {
         const bool qok = (uint32_t) tid < q_count;
         const uint32_t slot = p.q_slots[grp.q_begin + (qok ? (uint32_t) tid : 0u)];
-        const uint64_t tau = p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
+        const uint64_t tau = !SAMPLE && p.tau_init ? p.tau_init[slot] : KEY_EMPTY;
         const bool open = tau == KEY_EMPTY;
         const float lim = open ? __builtin_inff() : mono_to_float((uint32_t) (tau >> 32));
         const float qn = p.q_norm2[slot];
-        const int32_t c0 = !qok ? -0x40000000 : open ? 0x3FFFFFFF : (((int32_t) lim - (int32_t) qn) + 1) >> 1;
+        const int32_t c0 = SAMPLE ? 0 : !qok ? -0x40000000 : open ? 0x3FFFFFFF : (((int32_t) lim - (int32_t) qn) + 1) >> 1;
         colc[tid] = make_float4(__int_as_float(c0), qn, __uint_as_float(qok ? slot : 0xFFFFFFFFu), 0.0f);
     }
     __syncthreads();
@@ -270,6 +275,9 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
             issue((uint32_t) s3, (uint32_t) __builtin_amdgcn_readlane((int) px, 2 * s3), (uint32_t) __builtin_amdgcn_readlane((int) px, 2 * s3 + 1));
     }
 
+    int64_t smin[NQG];                                                          // SAMPLE: per column of this lane, (value, row)
+#pragma unroll
+    for (int j = 0; j < NQG; ++j) smin[j] = ((int64_t) 0x3FFFFFFF << 32);
     for (uint32_t i = 0; i < n_w; ++i) {
         const uint32_t ph = i % KI_CHUNK;
         // stage i has landed when at most the ten operations of stages i + 1 and i + 2 are outstanding (anything else in the
@@ -293,7 +301,10 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
         const uint32_t slot_ = i & (KI_SLOTS - 1);
         const float* nrm = nring + slot_ * KI_ROWS;
         const uint32_t m32 = (uint32_t) __builtin_amdgcn_readlane((int) cm, e) | ((uint32_t) __builtin_amdgcn_readlane((int) cm, e + 1) << 16);
-        if (lane < KI_ROWS) thr[lane] = (m32 >> lane) & 1u ? ((int32_t) nrm[lane]) >> 1 : 0x7FFFFFFF;
+        if (lane < KI_ROWS) {
+            if constexpr (SAMPLE) thr[lane] = (m32 >> lane) & 1u ? (int32_t) nrm[lane] : 0x3FFFFFFF;     // |row|^2 itself; no row: never the minimum
+            else thr[lane] = (m32 >> lane) & 1u ? ((int32_t) nrm[lane]) >> 1 : 0x7FFFFFFF;
+        }
 
         // ---- 2 row blocks x NQG query groups x 2 k-steps ----
         i32x4 acc[2][NQG];
@@ -319,6 +330,25 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
         }
 
         // ---- epilogue: acc[rb][j][r] = row rb * 16 + kq * 4 + r of the stage, query column j * 16 + li ----
+        if constexpr (SAMPLE) {
+            // smallest (|x'|^2 - 2 x'.q', row) of this lane's pairs of every column, as one signed 64-bit compare
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const i32x4 nx = __builtin_bit_cast(i32x4, reinterpret_cast<const uint4*>(thr)[rb * 4 + kq]);
+                const uint32_t x_rb = (uint32_t) __builtin_amdgcn_readlane((int) cx, e + rb);
+#pragma unroll
+                for (int j = 0; j < NQG; ++j)
+                    if ((uint32_t) j < ngt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int32_t w = nx[r] - 2 * acc[rb][j][r];          // (no row: 0x3FFFFFFF - 2 dot, above every real value)
+                            const int64_t cand = ((int64_t) w << 32) | (int64_t) (x_rb + (uint32_t) (kq * 4 + r));
+                            smin[j] = cand < smin[j] ? cand : smin[j];
+                        }
+                    }
+            }
+            continue;
+        }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const i32x4 th = __builtin_bit_cast(i32x4, reinterpret_cast<const uint4*>(thr)[rb * 4 + kq]);
@@ -371,7 +401,24 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
         }
         if (n_park >= (uint32_t) KI_FLUSH_AT) flush();
     }
-    if (n_park) flush();
+    if constexpr (SAMPLE) {
+        // the stream is over: every lane's minima go to their queries' sample buffers (returning atomics: only here)
+#pragma unroll
+        for (int j = 0; j < NQG; ++j) {
+            const int32_t w = (int32_t) (smin[j] >> 32);
+            if ((uint32_t) j < ngt && w < 0x20000000) {
+                const f32x4 cc = __builtin_bit_cast(f32x4, reinterpret_cast<const uint4*>(colc)[j * 16 + li]);
+                const uint32_t slot = __float_as_uint(cc[2]);
+                if (slot != 0xFFFFFFFFu) {
+                    const uint32_t row = (uint32_t) smin[j];
+                    const float v = (float) w + cc[1];                             // integers below 2^24: the fp32 distance
+                    const uint32_t at = atomicAdd(p.qcnt + slot, 1u);
+                    if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = make_key(v, g_rank ? g_rank[row] : row);
+                }
+            }
+        }
+    } else if (n_park)
+        flush();
     if (bad_row) atomicOr(p.err, 1u);                                           // a tile reached past the corpus: results invalid
     // the stages still in flight write LDS: they must have landed before the workgroup gives its LDS back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -379,8 +426,7 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
 
 inline hipError_t launch_i8_stream(const ScanParams& p, uint32_t n_blocks, hipStream_t s)
 {
-    if (p.plane_ho != 2 || p.pstride4 != 8 || p.rw != 16 || p.sample_stride > 1 || p.qmax > (uint32_t) KI_NQ || !p.ones)
-        return hipErrorInvalidValue;
+    if (p.plane_ho != 2 || p.pstride4 != 8 || p.rw != 16 || p.qmax > (uint32_t) KI_NQ || !p.ones) return hipErrorInvalidValue;
     const size_t lds = i8s_lds_bytes();
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -388,6 +434,7 @@ inline hipError_t launch_i8_stream(const ScanParams& p, uint32_t n_blocks, hipSt
         hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(KI_THREADS), lds, s, p);
         return hipGetLastError();
     };
+    if (p.sample_stride > 1) return launch(i8_stream_kernel<4, true>);         // (sample groups never exceed 64 columns)
     return p.qmax > 64 ? launch(i8_stream_kernel<8>) : launch(i8_stream_kernel<4>);
 }
 

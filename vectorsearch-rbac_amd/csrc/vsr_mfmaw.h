@@ -814,7 +814,7 @@ hipError_t launch_mfmaw_metric(const ScanParams& p, uint32_t n_blocks, hipStream
         constexpr int D = mw_depth(N);
         if (p.plane_ho == 2) {
             if constexpr (N == 1 && METRIC == M_L2) {                          // int8 planes: d <= 128, L2
-                if (few && p.k2i) return launch_i8_stream(p, n_blocks, s);     // per-wave streams (vsr_i8s.h)
+                if ((few && (p.k2i & 1u)) || (sample && (p.k2i & 2u))) return launch_i8_stream(p, n_blocks, s);   // per-wave streams (vsr_i8s.h)
                 return sample ? launch(mfma_wide_kernel<METRIC, 1, true, 2, mw_sample_depth(1, 2)>)
                               : few ? launch(mfma_wide_kernel<METRIC, 1, false, 2, VSR_MW_DEPTH8, 1>)
                                     : launch(mfma_wide_kernel<METRIC, 1, false, 2, VSR_MW_DEPTH8>);

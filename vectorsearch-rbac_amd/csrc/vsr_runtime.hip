@@ -182,6 +182,7 @@ struct vsr_ctx {
     bool no_k2i = true;            // VSR_K2I=1: the int8 main launch as K2i's per-wave streams instead of K2w's workgroup tiles (A/B;
                                    // measured on the headline step: K2w 0.342 ms, K2i 0.366 ms -- K2w stays the default)
     bool last_k2i = false;         // the last main launch was eligible for K2i
+    bool k2i_sample = true;        // VSR_NO_K2I_SAMPLE=1: the int8 sample pass on K2w's kernel instead of K2i's streams (A/B)
     bool no_scan8 = false;         // VSR_NO_SCAN8=1: one-query calls on the fp32 rows even when the int8 planes apply (A/B)
     bool k2i_wide = false;         // VSR_K2I_WIDE=1 (with VSR_K2I=1): 128-column passes on K2i
     int  force_epi = -1;           // VSR_FORCE_EPI=0|1: the main launch's survivor handling regardless of the estimate (tests)
@@ -335,6 +336,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     if ((env = getenv("VSR_FORCE_EPI"))) ctx->force_epi = atoi(env) != 0;
     if ((env = getenv("VSR_K2I_WIDE"))) ctx->k2i_wide = atoi(env) != 0;
     if ((env = getenv("VSR_NO_SCAN8"))) ctx->no_scan8 = atoi(env) != 0;
+    if ((env = getenv("VSR_NO_K2I_SAMPLE"))) ctx->k2i_sample = atoi(env) == 0;
     if ((env = getenv("VSR_NO_CLASSES"))) ctx->no_classes = atoi(env) != 0;
     if ((env = getenv("VSR_DEBUG"))) ctx->debug = (uint32_t) atoi(env);
     if ((env = getenv("VSR_NO_SEED"))) ctx->seeding = atoi(env) == 0;
@@ -1113,6 +1115,7 @@ struct Plan {
     std::vector<SelectQuery> sel1;           // level-1 K5 items (only for queries with many partial lists)
     std::vector<SelectQuery> selq;           // final K5 item per query (slot order)
     std::vector<ScanGroup>   groups_s;       // sample pass (threshold seeding): same passes, fewer workgroups
+    bool                     k2i_sample = false;   // int8 planes: the sample pass runs as K2i's per-wave streams (vsr_i8s.h, SAMPLE)
     std::vector<SelectQuery> seedq;          // per query: merge the sample pass's lists into a seed threshold
     uint32_t                 n_blocks_s = 0;
     uint32_t                 n_partial_s = 0;
@@ -1129,7 +1132,7 @@ struct Plan {
 
     void reset()                             // keeps the vectors' capacity: one plan per batch, no allocation once warm
     {
-        q_slots.clear(); groups.clear(); list_ids.clear(); block_map.clear(); n_launch = 0; sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear();
+        q_slots.clear(); groups.clear(); list_ids.clear(); block_map.clear(); n_launch = 0; sel1.clear(); selq.clear(); groups_s.clear(); seedq.clear(); k2i_sample = false;
         n_blocks = 0; qi = 1; mq = false; k2 = false; k2w = false; int8 = false; k2g = false; keep = 0; rerank_base = 0; n_scan_lists = 0; qmax = 1;
         n_blocks_s = 0; n_partial_s = 0; n_partial = 0; scan_rows = 0; scan_bytes = 0; sel_wave = false;
         scan_pairs = 0; unique_rows = 0; kp_frac = 0; sample_stride = 1;
@@ -1449,6 +1452,46 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
         // K2g on a small corpus: its 256-row tiles make a thin sample; it is sampled more densely (stride 8, 4, 2) before
         // the plan is given up.  (At the sizes it is built for -- millions of rows -- the first stride holds.)
         bool ok = false;
+        if (plan.int8 && ctx->k2i_sample && c->shape.rw == 16) {
+            // The sample pass as per-wave streams (vsr_i8s.h, SAMPLE): stages of 32 rows, every ss-th stage of a workgroup's
+            // range; each of the <= 4 waves that get a stage keeps 4 lanes' minima per query column over its whole stream.
+            // Fewer entries than K2w's per-tile minima, so the plan takes it only when every query's sample stays thick enough.
+            const double ss = ctx->sample_stride;
+            double frac = 1.0 / ss;
+            for (const ScanGroup& gs : plan.groups_s) {
+                const double t32 = std::ceil((double) gs.n_tiles * c->shape.rw / 32.0);
+                const double per_block = std::ceil(t32 / gs.n_blocks);
+                const double sampled = std::min(t32, gs.n_blocks * std::ceil(per_block / ss));
+                if (t32 > 0) frac = std::max(frac, sampled / t32);
+            }
+            const double lambda = (double) plan.keep * frac;
+            const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
+            est.assign((size_t) nq, 0.0);
+            for (size_t gi = 0; gi < plan.groups_s.size(); ++gi) {
+                const ScanGroup& gs = plan.groups_s[gi];
+                const double t32 = std::ceil((double) gs.n_tiles * c->shape.rw / 32.0);
+                const double per_block = std::floor(t32 / gs.n_blocks);                  // (the shortest block of the group)
+                const double st = std::max(1.0, std::ceil(per_block / ss));              // stages a workgroup samples
+                const double waves = std::min(4.0, st);
+                const double rows_per_entry = st / waves * 8.0;                          // 2 row blocks x 4 rows per lane and stage
+                const double p_entry = std::min(1.0, gdens_s[gi] * rows_per_entry);
+                for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += gs.n_blocks * waves * 4.0 * p_entry;
+            }
+            bool thick = seed_m <= GQ_SAMPLE_CAP / 4;
+            for (uint32_t q = 0; q < (uint32_t) nq && thick; ++q) {
+                const vsr_filter* f = fof(q);
+                const int64_t allowed = f ? f->allowed_rows : c->n;
+                const bool exact_count = !f || f->allowed_rows == f->scanned_rows;
+                if (allowed > (int64_t) GQ_CAP && est[q] < (exact_count ? 1.5 * seed_m + 16.0 : 2.5 * seed_m)) thick = false;
+            }
+            if (thick) {
+                ok = true;
+                plan.k2i_sample = true;
+                plan.sample_stride = ctx->sample_stride;
+                plan.kp_frac = (float) lambda;
+                for (ScanGroup& gs : plan.groups_s) gs.partial_begin = 0u;
+            }
+        }
         for (uint32_t stride = ctx->sample_stride; !ok && stride >= 2; stride = plan.k2g ? stride / 2 : 0) {
             plan.sample_stride = stride;
             const double ss = stride;
@@ -1780,6 +1823,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.qcand = ctx->d_samp.as<uint64_t>();
         sp.qcnt = scnt;
         sp.capq = GQ_SAMPLE_CAP;
+        sp.k2i = plan.k2i_sample ? 2u : 0u;                 // (bit 1: the sample launch on K2i; bit 0: the main launch)
         HIPCHK(launch_pass(plan.n_blocks_s));
         HIPCHK(launch_seed_select(ctx->d_samp.as<uint64_t>(), scnt, GQ_SAMPLE_CAP, plan.kp_frac, ctx->d_tau.as<uint64_t>(),
                                   (uint32_t) nq, ctx->stream));
