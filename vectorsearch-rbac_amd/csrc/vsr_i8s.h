@@ -53,8 +53,8 @@ constexpr int KI_NQ = 128;                 // query columns of a pass, at most (
 // (2 chunks) | parked candidates {value, row, column} | per-column counts]; per workgroup: [column constants]
 constexpr size_t KI_WAVE_BYTES = (size_t) KI_SLOTS * KI_STAGE_U4 * 16 + KI_SLOTS * KI_ROWS * 4 + KI_ROWS * 4 + 3 * 2 * (2 * KI_CHUNK) * 4 +
                                  2 * 4 * (2 * KI_CHUNK) * 4 + KI_PARK * 12 + KI_NQ * 4;
-inline size_t i8s_lds_bytes() { return KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16; }
-static_assert(2 * (KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16) <= 160 * 1024, "two workgroups per CU");
+inline size_t i8s_lds_bytes() { return KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16 + 16; }
+static_assert(2 * (KI_WAVES * KI_WAVE_BYTES + KI_NQ * 16 + 16) <= 160 * 1024, "two workgroups per CU");
 
 // SAMPLE: the threshold-seeding pass (ScanParams::sample_stride > 1): every ss-th stage of the workgroup's range, no
 // thresholds; every lane keeps the smallest (value, row) of each of its query columns over the wave's whole stream and
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
     uint32_t* pk_c = pk_r + KI_PARK;                                            //                    query column
     uint32_t* pk_n = pk_c + KI_PARK;                                            // [NC] candidates per column, then their first positions
     float4*   colc = reinterpret_cast<float4*>(smem + KI_WAVES * KI_WAVE_BYTES);   // [NC] {c0 bits, |q|^2, slot bits, -}
+    uint32_t* s_done = reinterpret_cast<uint32_t*>(colc + KI_NQ);                // SAMPLE: waves of the workgroup whose stream is over
     constexpr int NC = NQG * 16;                                                // query columns of this instantiation
 
     // ---- this wave's stages: stage i of the wave = list tiles t0 + 2 (wave + 4 i) + {0, 1} of the workgroup's range ----
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
     }
 
     // ---- query columns: the thresholds folded into what the integer accumulators start from (vsr_mfmaw.h, ITEST) ----
+    if (tid == 0) *s_done = 0u;
     if (tid < NC) {
         const bool qok = (uint32_t) tid < q_count;
         const uint32_t slot = p.q_slots[grp.q_begin + (qok ? (uint32_t) tid : 0u)];
@@ -402,18 +404,53 @@ __global__ __launch_bounds__(KI_THREADS, 2) void i8_stream_kernel(const ScanPara
         if (n_park >= (uint32_t) KI_FLUSH_AT) flush();
     }
     if constexpr (SAMPLE) {
-        // the stream is over: every lane's minima go to their queries' sample buffers (returning atomics: only here)
+        // The stream is over.  Every lane's minima go to its wave's (now idle) stage ring; the LAST wave of the workgroup to
+        // get here appends all of them: one returning atomic per query column and workgroup, like K2w's sample pass
+        // (atomics on one address serialise at ~0.2 us each: per-lane appends made this launch 8 x longer than K2w's).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the ring is about to be reused
+        uint64_t* mine = reinterpret_cast<uint64_t*>(ring);                     // [NC][4]: column, row quad
 #pragma unroll
         for (int j = 0; j < NQG; ++j) {
             const int32_t w = (int32_t) (smin[j] >> 32);
+            uint64_t key = KEY_EMPTY;
             if ((uint32_t) j < ngt && w < 0x20000000) {
                 const f32x4 cc = __builtin_bit_cast(f32x4, reinterpret_cast<const uint4*>(colc)[j * 16 + li]);
-                const uint32_t slot = __float_as_uint(cc[2]);
-                if (slot != 0xFFFFFFFFu) {
-                    const uint32_t row = (uint32_t) smin[j];
-                    const float v = (float) w + cc[1];                             // integers below 2^24: the fp32 distance
-                    const uint32_t at = atomicAdd(p.qcnt + slot, 1u);
-                    if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = make_key(v, g_rank ? g_rank[row] : row);
+                const uint32_t row = (uint32_t) smin[j];
+                if (__float_as_uint(cc[2]) != 0xFFFFFFFFu) key = make_key((float) w + cc[1], g_rank ? g_rank[row] : row);   // integers below 2^24: the fp32 distance
+            }
+            mine[(j * 16 + li) * 4 + kq] = key;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t arrived = 0;
+        if (lane == 0) arrived = atomicAdd(s_done, 1u);
+        arrived = (uint32_t) __shfl((int) arrived, 0);
+        const uint32_t active = n_st < (uint32_t) KI_WAVES ? n_st : (uint32_t) KI_WAVES;
+        if (arrived + 1u == active) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int c0 = 0; c0 < NC; c0 += 64) {
+                const int c = c0 + lane;
+                const uint32_t slot = __float_as_uint(colc[c].z);
+                uint64_t keys16[16];
+                uint32_t n = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < KI_WAVES; ++w2) {
+                    const uint64_t* other = reinterpret_cast<const uint64_t*>(smem + (size_t) w2 * KI_WAVE_BYTES);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const uint64_t kk = (uint32_t) w2 < active ? other[c * 4 + q4] : KEY_EMPTY;
+                        keys16[w2 * 4 + q4] = kk;
+                        n += kk != KEY_EMPTY;
+                    }
+                }
+                if (n && slot != 0xFFFFFFFFu) {
+                    uint32_t at = atomicAdd(p.qcnt + slot, n);
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (keys16[t] != KEY_EMPTY) {
+                            if (at < p.capq) p.qcand[(size_t) slot * p.capq + at] = keys16[t];
+                            ++at;
+                        }
                 }
             }
         }
