@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--sharding", default="auto", choices=["auto", "placement", "rows"],
                     help="N > 1: 'placement' = whole role partitions on GPUs, a query touches ONE GPU, no exchange (SURVEY 8e-ii); "
                          "'rows' = contiguous row ranges, every query on every GPU, all-gather + merge (SURVEY 8e-i); auto = placement")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1 under role placement: weak = N x 1000 queries per step (every GPU answers ~1000, the N = 1 step's "
+                         "work; default), strong = the same 1000-query step as N = 1 spread over the GPUs")
     ap.add_argument("--wiki-rows", type=int, default=5_000_000, help="rows of the 768-d legs' corpus (0: skip the legs)")
     ap.add_argument("--wiki-steps", type=int, default=5)
     ap.add_argument("--index-rows", type=int, default=120_000, help="rows of the role partition the HNSW legs (CPU port and K4) index")
@@ -425,8 +428,9 @@ def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim
     partition tables of a user's role combination): every ROLE lives on one GPU together with everything it can see (its
     own permission class and its ancestors': the few classes near the root are replicated on the GPUs that host a
     descendant), so a query is answered by ONE GPU from its resident rows and there is no data-path collective at all.
-    The step is the same 1000-query batch as at N = 1; each rank searches the queries of its roles.  Strong scaling:
-    total work fixed, value = 1000 x steps / the slowest rank's time."""
+    Weak scaling (default): a step is N x 1000 queries drawn like the N = 1 step's, each rank searches those of its roles
+    (about 1000: the N = 1 step's work on every GPU), value = N x 1000 x steps / the slowest rank's time.  --scaling strong:
+    the step is the same 1000-query batch as at N = 1.  The other mode is reported as a sibling record either way."""
     from vsrbac.datasets import sample_queries, sift_like_rows_at, tree_rbac
     n, dim, k, nq = args.rows, args.dim, args.k, args.queries
     parts = world if world > 1 else sim_world
@@ -447,11 +451,25 @@ def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim
     x = sift_like_rows_at(rows_idx, dim, args.seed)
     blk, doc = rows_idx + 1, (rows_idx // 100 + 1).astype(np.int32)
     nb = max(1, min(args.batches, args.steps + args.warmup))
-    batches = []
-    for b in range(nb):
-        qrow, quser = sample_queries(nq, n, 1000, seed=args.seed + 1000 * b)
-        mine = np.flatnonzero(np.array([where[role_of[int(u)]] == me for u in quser]))
-        batches.append((qrow[mine], quser[mine]))
+    weak = args.scaling == "weak" and parts > 1
+
+    def draw(mult, count, seed0):
+        """`count` batches of mult x nq queries drawn like the N = 1 step's; this rank keeps those of its roles."""
+        made = []
+        for b in range(count):
+            qr, qu = [], []
+            for j in range(mult):
+                qrow, quser = sample_queries(nq, n, 1000, seed=args.seed + 1000 * (seed0 + b * mult + j))
+                mine = np.flatnonzero(np.array([where[role_of[int(u)]] == me for u in quser]))
+                qr.append(qrow[mine])
+                qu.append(quser[mine])
+            made.append((np.concatenate(qr), np.concatenate(qu)))
+        return made
+
+    # weak scaling (the default for N > 1): a step is N x 1000 queries, so every rank answers about 1000 -- the N = 1 step's
+    # work per GPU; strong scaling (--scaling strong, and the sibling record of a weak run): the same 1000-query step as N = 1
+    batches = draw(parts, nb, 0) if weak else draw(1, nb, 0)
+    nq_step = nq * parts if weak else nq
     qvecs = [sift_like_rows_at(qr, dim, args.seed) if len(qr) else np.zeros((0, dim), np.float32) for qr, _ in batches]
     t_gen = time.time() - t0
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
@@ -539,38 +557,35 @@ def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim
         s_steps = max(args.steps, int(args.sustained_s / max(head["dt"] / args.steps, 1e-6)))
         s_steps = int(reduce(float(s_steps), dist.ReduceOp.MAX if world > 1 else None))      # the same count on every rank
         srun = timed_leg(legs[0], s_steps, 1)
-        sustained = {"steps": s_steps, "seconds": round(srun["dt"], 3), "value": round(nq * s_steps / srun["dt"], 1),
+        sustained = {"steps": s_steps, "seconds": round(srun["dt"], 3), "value": round(nq_step * s_steps / srun["dt"], 1),
                      "ms_per_step": round(srun["dt"] / s_steps * 1e3, 4)}
-    # Sibling record, NOT the headline: the same ranks under a load N times as dense -- a step is N x 1000 queries, every rank
-    # searches the ~1000 of its roles in one call.  A shard's 1000-query step above is mostly per-call fixed cost (five
-    # launches for ~125 queries); this is what the placement delivers once each GPU's queue fills a batch of its own.
-    saturated = None
-    if os.environ.get("VSR_BENCH_NO_SATURATED") != "1":
+    # Sibling record, NOT the headline: the other scaling mode on the same ranks.  Under weak scaling (default) that is the
+    # N = 1 step's own 1000 queries spread over the ranks (strong scaling: a rank's ~1000 / N-query call is mostly per-call
+    # fixed cost, five launches for ~125 queries); under --scaling strong it is the N x 1000-query step.
+    sibling = None
+    if parts > 1 and os.environ.get("VSR_BENCH_NO_SIBLING") != "1":
         nbs = max(1, min(4, nb))
-        sat = []
-        for b in range(nbs):
-            qr, qu = [], []
-            for j in range(parts):
-                qrow, quser = sample_queries(nq, n, 1000, seed=args.seed + 1000 * (nb + b * parts + j))
-                mine = np.flatnonzero(np.array([where[role_of[int(u)]] == me for u in quser]))
-                qr.append(qrow[mine])
-                qu.append(quser[mine])
-            sat.append((np.concatenate(qr), np.concatenate(qu)))
+        other = draw(1, nbs, 500) if weak else draw(parts, nbs, 500)
         saved = (batches, d_qs, filt, outs, nb)
-        batches = sat
+        batches = other
         nb = nbs
-        d_qs = [torch.from_numpy(np.ascontiguousarray(sift_like_rows_at(qr, dim, args.seed))).to(dev) for qr, _ in sat]
-        filt = {legs[0]: [corpus.pack_filters([corpus.filter_for_user(int(u), MODES[legs[0]]) for u in qu]) for _, qu in sat]}
-        mq2 = max(len(qr) for qr, _ in sat)
+        d_qs = [torch.from_numpy(np.ascontiguousarray(sift_like_rows_at(qr, dim, args.seed))).to(dev) if len(qr)
+                else torch.zeros((1, dim), device=dev) for qr, _ in other]
+        filt = {legs[0]: [corpus.pack_filters([corpus.filter_for_user(int(u), MODES[legs[0]]) for u in qu]) for _, qu in other]}
+        mq2 = max(1, max(len(qr) for qr, _ in other))
         outs = [{"blk": torch.empty((mq2, k), dtype=torch.int64, device=dev), "doc": torch.empty((mq2, k), dtype=torch.int32, device=dev),
                  "row": torch.empty((mq2, k), dtype=torch.int64, device=dev), "dist": torch.empty((mq2, k), dtype=torch.float32, device=dev),
                  "cnt": torch.empty((mq2,), dtype=torch.int32, device=dev)} for _ in range(n_sess)]
         try:
             sr = timed_leg(legs[0], args.steps, args.warmup)
+            nq_other = nq if weak else nq * parts
             if sr["flagged"] == 0:
-                saturated = {"queries_per_step_all_ranks": int(nq * parts), "queries_per_step_this_rank": int(np.mean([len(q) for q, _ in sat])),
-                             "ms_per_step": round(sr["dt"] / args.steps * 1e3, 4), "value": round(nq * parts * args.steps / sr["dt"], 1),
-                             "unit": "queries/s", "note": "NOT the headline and not strong scaling: N x 1000 queries per step"}
+                sibling = {"scaling": "strong" if weak else "weak", "queries_per_step_all_ranks": int(nq_other),
+                           "queries_per_step_this_rank": int(np.mean([len(q) for q, _ in other])),
+                           "ms_per_step": round(sr["dt"] / args.steps * 1e3, 4), "value": round(nq_other * args.steps / sr["dt"], 1),
+                           "unit": "queries/s",
+                           "note": ("NOT the headline: the N = 1 step's 1000 queries spread over the ranks (total work fixed)" if weak
+                                    else "NOT the headline: N x 1000 queries per step (per-GPU work fixed)")}
         finally:
             batches, d_qs, filt, outs, nb = saved
     # parity (default on): this rank's first queries of batch 0 against the oracle over the rows it holds -- by
@@ -596,15 +611,16 @@ def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim
         roof["note"] = "rank 0's main scan launches (its roles' rows); " + roof.get("note", "")
         out = {
             "metric": "QPS at recall@100, SIFT10M filtered-kNN (role RBAC), 1/2/4/8 MI355X",
-            "value": round(nq * args.steps / head["dt"], 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "value": round(nq_step * args.steps / head["dt"], 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(head["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
+            "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": ("int8 planes -> i32 (exact: bit-identical to the fp32 distances of vector.c)" if "int8" in head["kernel"]
                       else "bf16 planes -> f32 (screen), f32 exact re-rank" if "K2" in head["kernel"] else "f32"),
             "data": "synthetic",
             "config": {"workload": f"SIFT10M-like {n}x{dim} fp32 L2 k={k}, tree RBAC 1000 users/100 roles, role-partition "
-                                   f"{legs[0]}, exact filtered top-k, {nq} queries/step ({nb} distinct batches)",
-                       "rows": n, "dim": dim, "k": k, "queries_per_step": nq, "filter": legs[0],
+                                   f"{legs[0]}, exact filtered top-k, {nq_step} queries/step over all ranks "
+                                   f"({nb} distinct batches)" + (f": {nq} per GPU, the N = 1 step's work on every GPU" if weak else ""),
+                       "rows": n, "dim": dim, "k": k, "queries_per_step": nq_step, "filter": legs[0],
                        "sharding": f"role placement x{parts}: every role (and all it can see) on one GPU, a query touches one "
                                    f"GPU, no exchange", "exchange": "none (no data-path collective)",
                        "recall": 1.0 if ok_all else None, "batches_in_flight": n_sess},
@@ -623,12 +639,12 @@ def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim
         }
         for leg in legs[1:]:
             r = results[leg]
-            out[leg] = {"value": round(nq * args.steps / r["dt"], 1), "unit": "queries/s", "ms_per_step": round(r["dt"] / args.steps * 1e3, 4),
+            out[leg] = {"value": round(nq_step * args.steps / r["dt"], 1), "unit": "queries/s", "ms_per_step": round(r["dt"] / args.steps * 1e3, 4),
                         "roofline": roofline_of(r["stats"], dim, r["kernel"], n_sess)}
         if sustained:
             out["sustained"] = sustained
-        if saturated:
-            out["saturated_load"] = saturated
+        if sibling:
+            out["strong_scaling" if weak else "weak_scaling"] = sibling
         if world == 1:
             out["sim_world"] = {"parts": parts, "simulated_rank": me, "note": "ONE rank's share of the N-GPU job on one GPU (the "
                                 "rank with the largest predicted load unless VSR_BENCH_SIM_RANK says otherwise)"}
@@ -1080,22 +1096,38 @@ def main():
                                     "note": "one query per call, back to back on one stream; not the headline"}
 
         # the brute-force distance kernel on its own (north_star: ">= 60 % HBM roofline on the brute-force distance
-        # kernel"): K1, one unfiltered query over the whole corpus = every fp32 row once, HIP events on the launch stream
-        ctx.profiling(2)
-        ctx.stats_reset()
-        for i in range(10):
-            corpus.search_device(ptr(d_qs[0][i:i + 1]), 1, k, "l2", None, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
-                                 ptr(d_cnt), ptr(d_keys))
-        st1 = ctx.stats()
-        ctx.profiling(False)
-        if st1["scan_launches"][0]:
-            bf_ms = st1["scan_ms"][0] / st1["scan_launches"][0]
-            bf_bytes = (hi - lo) * (dim * 4) + k * 12
-            out["brute_force_scan"] = {"kernel": ctx.last_scan_kernel(), "rows": int(hi - lo), "bytes": int(bf_bytes),
-                                       "launch_ms": round(bf_ms, 4), "achieved_gbs": round(bf_bytes / bf_ms / 1e6, 1),
-                                       "frac_of_8TBs": round(bf_bytes / bf_ms / 1e6 / HBM_PEAK_GBS, 4),
-                                       "note": "one query, no filter, fp32 rows (SURVEY 8d: rows * d * 4 + k * 12 bytes); the "
-                                               "launch includes the in-kernel merge of the workgroups' lists"}
+        # kernel"): K1, one unfiltered query over the whole corpus, HIP events on the launch stream.  Two forms, each priced
+        # at the bytes ITS kernel reads: the fp32 rows (rows * d * 4 + k * 12; what any corpus gets) and, for
+        # this u8-valued corpus under the query hint, the int8 planes (rows * (128 + 4)).
+        hinted = os.environ.get("VSR_BENCH_NO_U8_HINT") != "1"
+        for name, hint in (("brute_force_scan", False), ("brute_force_scan_int8_planes", True)):
+            if hint and not hinted:
+                continue
+            ctx.set_query_hint(hint)
+            for i in range(3):
+                corpus.search_device(ptr(d_qs[0][i:i + 1]), 1, k, "l2", None, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
+                                     ptr(d_cnt), ptr(d_keys))
+            torch.cuda.synchronize()
+            ctx.profiling(2)
+            ctx.stats_reset()
+            for i in range(10):
+                corpus.search_device(ptr(d_qs[0][i:i + 1]), 1, k, "l2", None, ptr(d_blk), ptr(d_doc), ptr(d_row), ptr(d_dist),
+                                     ptr(d_cnt), ptr(d_keys))
+            st1 = ctx.stats()
+            ctx.profiling(False)
+            if st1["scan_launches"][0]:
+                kern = ctx.last_scan_kernel()
+                on8 = "int8" in kern
+                bf_ms = st1["scan_ms"][0] / st1["scan_launches"][0]
+                bf_bytes = (hi - lo) * ((128 + 4) if on8 else dim * 4) + k * 12
+                out[name] = {"kernel": kern, "rows": int(hi - lo), "bytes": int(bf_bytes),
+                             "launch_ms": round(bf_ms, 4), "achieved_gbs": round(bf_bytes / bf_ms / 1e6, 1),
+                             "frac_of_8TBs": round(bf_bytes / bf_ms / 1e6 / HBM_PEAK_GBS, 4),
+                             "note": ("one query, no filter; bytes = rows * (128 B int8 plane + 4 B |row|^2) + k * 12: what this "
+                                      "kernel reads" if on8 else
+                                      "one query, no filter, fp32 rows (SURVEY 8d: rows * d * 4 + k * 12 bytes)") +
+                                     "; the launch includes the in-kernel merge of the workgroups' lists"}
+        ctx.set_query_hint(hinted)
 
         # the boundary's host-buffer form (vsr_search: queries in, results out over PCIe, synchronous, flagged queries
         # re-run inside the call), whole 1000-query batches; and the synchronous harness call, one query at a time
