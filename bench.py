@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--sustained-s", type=float, default=2.0, help="extra untimed-by-the-driver leg: seconds of steps")
     ap.add_argument("--cpu-queries", type=int, default=1000, help="sample size of the CPU baseline leg")
     ap.add_argument("--cpu-reps", type=int, default=2, help="repetitions of the CPU sample (10-30 s of CPU work)")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r2", "traffic.json"),
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r3", "traffic.json"),
                     help="PMC-derived HBM bytes per launch (tools/pmc_traffic.py) for roofline.traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the VSR_NO_INT8 sibling record of the headline leg")
