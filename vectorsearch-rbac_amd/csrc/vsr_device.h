@@ -78,6 +78,7 @@ struct FusedTail {
     int32_t*        flag_total;    // the session's count of flagged queries (scan8: a query that broke the u8 promise); may be null
     uint32_t        row_offset;
     int             metric;
+    uint64_t*       dbg;           // development (VSR_FUSED_DBG=1): 100 MHz timestamps of the workgroup that finishes the call; nullptr otherwise
 };
 
 struct ScanParams {

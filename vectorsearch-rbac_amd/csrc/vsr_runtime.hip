@@ -151,6 +151,8 @@ struct vsr_ctx {
     int64_t flagged_seen = 0;
     DevBuf d_out;        // host-API outputs
     DevBuf d_misc;
+    DevBuf d_dbg;                 // VSR_FUSED_DBG: timestamps of the one-query launch
+    PinBuf h_dbg;
     DevBuf d_done;                // nq == 1 fused path: arrival counters of the in-kernel merge tree (zero between calls)
     DevBuf d_redo;                // vsr_search_device_exact: queries and results of the flagged queries
     PinBuf h_desc;
@@ -164,6 +166,8 @@ struct vsr_ctx {
     vsr_stats stats{};
     // knobs
     int block_budget = 0;          // 0 = 4 * CUs
+    bool fused_dbg = false;        // VSR_FUSED_DBG=1
+    int fused_fan = 0;             // VSR_FUSED_FAN: lists per first-level merge of the one-query launch (0: the planner's rule)
     int min_rows_per_block = 256;
     int min_shared_rows = 2048;    // rows per workgroup of a shared pass (VSR_MIN_SHARED_ROWS)
     int max_qb = 16;               // queries per shared pass.  32 (two MFMA query groups) does not pay at d = 128; the planner
@@ -327,6 +331,8 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     HIPCHK(hipMemset(reinterpret_cast<char*>(ctx->d_flag_total) + 32, 0xFF, 8));   // ScanParams::ones
     const char* env;
     if ((env = getenv("VSR_BLOCK_BUDGET"))) ctx->block_budget = atoi(env);
+    if ((env = getenv("VSR_FUSED_FAN"))) ctx->fused_fan = atoi(env);
+    if ((env = getenv("VSR_FUSED_DBG"))) ctx->fused_dbg = atoi(env) != 0;
     if ((env = getenv("VSR_MIN_ROWS_PER_BLOCK"))) ctx->min_rows_per_block = std::max(1, atoi(env));
     if ((env = getenv("VSR_MAX_QB"))) { ctx->max_qb = std::max(1, atoi(env)); ctx->max_qb_set = true; }
     if ((env = getenv("VSR_NO_MQ"))) ctx->no_mq = atoi(env) != 0;
@@ -1990,7 +1996,8 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
         const uint32_t cap = std::max<uint32_t>(4096, scan_cap_for_k((int) kp, c->dim));   // the merge's LDS layout (vsr_scan.h, FUSED_*)
         const ScanGroup& g = plan.groups[0];
         const uint32_t per_merge = kp ? 8192u / kp : 0u;    // lists one merge takes (16 keys per thread, vsr_scan.h)
-        const uint32_t fan = per_merge ? std::max<uint32_t>(16, (g.n_blocks + per_merge - 1) / per_merge) : 0u;
+        uint32_t fan = per_merge ? std::max<uint32_t>(16, (g.n_blocks + per_merge - 1) / per_merge) : 0u;
+        if (ctx->fused_fan >= 16 && per_merge >= 16) fan = std::min<uint32_t>((uint32_t) ctx->fused_fan, per_merge);   // development knob (>= 16: d_done holds 256 group counters)
         if (kp <= 512 && fan && fan <= per_merge) {
             int rc;
             const uint32_t n_g = (g.n_blocks + fan - 1) / fan;
@@ -2046,6 +2053,20 @@ static int search_impl(vsr_ctx* ctx, vsr_corpus* c, const float* h_queries, cons
             sp.fused.out_flag = ctx->d_flags.as<int32_t>();
             sp.fused.row_offset = (uint32_t) idc->row_offset;
             sp.fused.metric = metric;
+            if (ctx->fused_dbg) {                           // development: timestamps of the finishing workgroup, printed by the next call
+                if (!ctx->d_dbg.p) {
+                    if ((rc = ctx->d_dbg.reserve(64))) return rc;
+                    if ((rc = ctx->h_dbg.reserve(64))) return rc;
+                } else {
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                    const uint64_t* t = ctx->h_dbg.as<uint64_t>();
+                    HIPCHK(hipMemcpy(ctx->h_dbg.p, ctx->d_dbg.p, 64, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "fused_dbg us: scan %.1f compact+publish %.1f wait %.1f merge1 %.1f publish+wait %.1f merge2 %.1f tail %.1f total %.1f\n",
+                            (t[1] - t[0]) / 100.0, (t[2] - t[1]) / 100.0, t[3] ? (t[3] - t[2]) / 100.0 : 0.0, t[3] ? (t[4] - t[3]) / 100.0 : 0.0,
+                            (t[5] - (t[4] ? t[4] : t[2])) / 100.0, (t[6] - t[5]) / 100.0, (t[7] - t[6]) / 100.0, (t[7] - t[0]) / 100.0);
+                }
+                sp.fused.dbg = ctx->d_dbg.as<uint64_t>();
+            }
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (ctx->profiling) {
                 e0 = take_event(ctx);

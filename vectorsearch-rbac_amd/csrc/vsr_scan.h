@@ -110,7 +110,7 @@ struct TileRegs {
 
 // ---- nq == 1: in-kernel merge tree (FusedTail, vsr_device.h) ----
 constexpr int FUSED_KPT = 16;                               // keys per thread of one merge: <= 8192 keys
-constexpr uint32_t FUSED_CLS = 1024;                        // a tie class this small is ranked directly
+constexpr uint32_t FUSED_CLS = 64;                          // a tie class this small is ranked directly (ranking is quadratic: 1024 cost 10-25 us)
 // LDS of a merge (in units of keys, inside the workgroup's top-k buffer of >= 4096 keys): the selected keys, the final
 // tie class, one digit histogram per wave, scalars
 constexpr uint32_t FUSED_OUT = 0, FUSED_CLS_AT = 512, FUSED_HIST_AT = 1536, FUSED_SC_AT = 2560;
@@ -248,10 +248,11 @@ __device__ __forceinline__ uint32_t fused_block_select(const uint64_t* src, uint
 // bad: the query broke a promise the kernel relied on (scan8: not integer-valued in 0..255): the result is written but FLAGGED
 // (negative count, flag word set), like a query the screening could not prove; the caller re-runs it on the exact path
 __device__ __forceinline__ void fused_tail(const ScanParams& p, const ScanGroup& grp, uint32_t local_block, uint64_t* keys,
-                                        int tid, bool bad = false)
+                                        int tid, bool bad = false, uint64_t t_start = 0, uint64_t t_scan = 0, uint64_t t_pub = 0)
 {
     __shared__ uint32_t s_last;
     const FusedTail& f = p.fused;
+    uint64_t t_m1 = 0, t_m1s = 0;
     const uint32_t B = grp.n_blocks, fan = f.fan, n_g = (B + fan - 1) / fan, k = p.k, kp = p.kp;
     const uint32_t my_g = local_block / fan;
     const uint32_t g_size = (my_g + 1) * fan <= B ? fan : B - my_g * fan;
@@ -268,7 +269,9 @@ __device__ __forceinline__ void fused_tail(const ScanParams& p, const ScanGroup&
     const uint64_t* src = lists;
     uint32_t n_src = B * kp;
     if (n_g > 1) {
+        if (f.dbg) t_m1s = wall_clock64();
         const uint32_t n = fused_block_select(lists + (size_t) my_g * fan * kp, g_size * kp, k, keys, tid);   // (the top-k buffer is free now)
+        if (f.dbg) t_m1 = wall_clock64();
         uint64_t* dst = lists + (size_t) (B + my_g) * kp;
         for (uint32_t i = tid; i < kp; i += SCAN_THREADS)
             __hip_atomic_store(dst + i, i < n ? keys[i] : KEY_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -279,25 +282,23 @@ __device__ __forceinline__ void fused_tail(const ScanParams& p, const ScanGroup&
         src = lists + (size_t) B * kp;
         n_src = n_g * kp;
     }
+    const uint64_t t_m2s = f.dbg ? wall_clock64() : 0;
     const uint32_t m = fused_block_select(src, n_src, k, keys, tid);
-    {                                                       // the caller's order: one wave sorts the k keys
-        uint32_t np2 = 2;
-        while (np2 < m) np2 <<= 1;
-        for (uint32_t i = m + (uint32_t) tid; i < np2; i += SCAN_THREADS) keys[i] = KEY_EMPTY;
-        __syncthreads();
-        if (tid < 64 && m > 1) bitonic_sort_wave(keys, np2, tid);
-        __syncthreads();
-    }
+    const uint64_t t_m2 = f.dbg ? wall_clock64() : 0;
+    // the caller's order: every thread that holds a key counts the keys below it (keys are unique; m <= 512 broadcast reads)
+    // and writes its row at that position -- no sorting network, no further barrier
     for (uint32_t i = tid; i < k; i += SCAN_THREADS) {
         if (i < m) {
             const uint64_t key = keys[i];
+            uint32_t at = 0;
+            for (uint32_t j = 0; j < m; ++j) at += keys[j] < key;
             const uint32_t row = (uint32_t) key;
             const float v = mono_to_float((uint32_t) (key >> 32));
-            f.out_block[i] = f.block_ids[row];
-            f.out_doc[i] = f.doc_ids[row];
-            if (f.out_row) f.out_row[i] = f.orig_rows[row];
-            f.out_dist[i] = f.metric == M_L2 ? (float) sqrt((double) v) : v;  // vector.c:577
-            if (f.out_keys) f.out_keys[i] = (key & 0xFFFFFFFF00000000ull) | (uint64_t) (row + f.row_offset);
+            f.out_block[at] = f.block_ids[row];
+            f.out_doc[at] = f.doc_ids[row];
+            if (f.out_row) f.out_row[at] = f.orig_rows[row];
+            f.out_dist[at] = f.metric == M_L2 ? (float) sqrt((double) v) : v;  // vector.c:577
+            if (f.out_keys) f.out_keys[at] = (key & 0xFFFFFFFF00000000ull) | (uint64_t) (row + f.row_offset);
         } else {
             f.out_block[i] = -1;
             f.out_doc[i] = -1;
@@ -312,6 +313,10 @@ __device__ __forceinline__ void fused_tail(const ScanParams& p, const ScanGroup&
         if (bad && f.flag_total) atomicAdd(f.flag_total, 1);
     }
     for (uint32_t i = tid; i < 1 + n_g; i += SCAN_THREADS) f.done[i] = 0;     // every other workgroup is past its counter
+    if (f.dbg && tid == 0) {
+        f.dbg[0] = t_start; f.dbg[1] = t_scan; f.dbg[2] = t_pub; f.dbg[3] = t_m1s; f.dbg[4] = t_m1; f.dbg[5] = t_m2s; f.dbg[6] = t_m2;
+        f.dbg[7] = wall_clock64();
+    }
 }
 
 // C > 0: compile-time chunk count.  C == 0: runtime chunk loop (any dimension; LPR = 64, qmax <= QI).
@@ -527,8 +532,16 @@ __global__ __launch_bounds__(SCAN_THREADS, VSR_MINWAVES) void scan_kernel(const 
     // ---- publish this workgroup's k best per query ----
     __syncthreads();
     for (uint32_t qs = 0; qs < q_count; ++qs) {
-        topk_compact<SCAN_THREADS>(keys + (size_t) qs * cap, &ctrl[qs], k, tid, false);
-        const uint32_t n = ctrl[qs].count < k ? ctrl[qs].count : k;
+        uint32_t n;
+        if (fused && ctrl[qs].count <= (uint32_t) (SCAN_THREADS * FUSED_KPT)) {
+            // one query per call: the k smallest UNORDERED by a radix select on registers (the merge does not need them sorted;
+            // the bitonic sort of ~1000 keys, 55 barriers, was a quarter of the call)
+            const uint32_t have = ctrl[qs].count;           // (everybody reads it before the select reuses the buffer)
+            n = have > k ? fused_block_select<true>(keys, have, k, keys, tid) : have;
+        } else {
+            topk_compact<SCAN_THREADS>(keys + (size_t) qs * cap, &ctrl[qs], k, tid, false);
+            n = ctrl[qs].count < k ? ctrl[qs].count : k;
+        }
         uint64_t* dst = p.partial + (size_t) (grp.partial_begin + qs * grp.n_blocks + local_block) * p.kp;
         if (fused) {                                        // device-scope stores: read by another workgroup of this launch
             for (uint32_t i = tid; i < p.kp; i += SCAN_THREADS)

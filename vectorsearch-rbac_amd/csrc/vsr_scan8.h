@@ -4,6 +4,10 @@
 
 namespace vsr {
 
+#ifndef SCAN8_DEPTH
+#define SCAN8_DEPTH 4          // tiles of a wave whose rows are in flight
+#endif
+
 // ---- K1 on the int8 planes: ONE query per call over a SIFT-like corpus (u8-exact rows, d <= 128, L2) ----
 // The one-query call (the reference harness's shape) is a scan of the query's role partition plus the in-kernel merge; on
 // the fp32 rows the scan is 512 bytes per row.  The int8 planes (x - 128, 128 bytes per row, |x - 128|^2 beside them) hold
@@ -17,6 +21,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan8_fused_kernel(const Scan
 {
     constexpr int RW = 16, XCHK = scan_slack(RW) / (SCAN_WAVES * RW);
     static_assert(XCHK >= 1, "append slack");
+    const uint64_t t_start = p.fused.dbg ? wall_clock64() : 0;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -26,7 +31,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan8_fused_kernel(const Scan
     const ScanGroup grp = p.fused.group;
     const auto g_tiles = as_global(grp.tiles);
     const auto g_bitmap = as_global(grp.bitmap);
-    const auto g_rank = as_global(p.rank);
     const uint32_t local_block = blockIdx.x;
     const uint32_t t0 = (uint32_t) (((uint64_t) grp.n_tiles * local_block) / grp.n_blocks);
     const uint32_t t1 = (uint32_t) (((uint64_t) grp.n_tiles * (local_block + 1)) / grp.n_blocks);
@@ -44,12 +48,18 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan8_fused_kernel(const Scan
     if (tid < 32) {                                          // four elements -> one word
         uint32_t word = 0, n2 = 0;
         bool bad = false;
+        float xs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                        // four loads in flight (clamped index), one wait
+            const uint32_t j = (uint32_t) tid * 4 + (uint32_t) e;
+            xs[e] = p.queries[j < dim ? j : 0u];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t j = (uint32_t) tid * 4 + (uint32_t) e;
             int b = 0;
             if (j < dim) {
-                const float x = p.queries[j];
+                const float x = xs[e];
                 bad |= !(x >= 0.0f && x <= 255.0f && x == floorf(x));
                 b = (int) fminf(fmaxf(x, 0.0f), 255.0f) - 128;
                 n2 += (uint32_t) (b * b);
@@ -68,83 +78,110 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan8_fused_kernel(const Scan
     const uint32_t iters = ((t1 - t0) + SCAN_WAVES - 1) / SCAN_WAVES;
     const uint32_t last_row = p.n_rows - 1u;
 
-    struct Tile { uint32_t start; uint32_t mask; uint4 x[2]; float rn[2]; };
-    auto fetch = [&](uint32_t t, Tile& tr) {
-        tr.mask = 0;
-        tr.start = 0;
-        tr.x[0] = tr.x[1] = make_uint4(0u, 0u, 0u, 0u);
-        tr.rn[0] = tr.rn[1] = 0.0f;
-        if (t >= t1) return;
-        uint2 tl;
-        if (g_tiles) tl = load_tile(g_tiles, t);
-        else {                                               // no filter: the identity tiling of the corpus
-            tl.x = t * RW;
-            tl.y = p.n_rows - tl.x < (uint32_t) RW ? p.n_rows - tl.x : (uint32_t) RW;
-        }
-        uint32_t mask = tl.y >= 16u ? 0xFFFFu : (1u << tl.y) - 1u;
-        if (g_bitmap) mask &= (uint32_t) bitmap_window(g_bitmap, tl.x);
-        tr.start = tl.x;
-        tr.mask = mask;
-        if (!mask) return;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t row = tl.x + (uint32_t) (r * 8 + g);
-            const bool ok = (mask >> (r * 8 + g)) & 1u;
-            const uint32_t rc = row <= last_row ? row : last_row;
-            tr.x[r] = ok ? p.scr[(size_t) rc * 8 + l] : make_uint4(0u, 0u, 0u, 0u);
-            tr.rn[r] = ok && l == 0 ? p.norm2[rc] : 0.0f;
-        }
-    };
-    Tile cur, nxt;
-    fetch(t0 + (uint32_t) wave, cur);
+    // A wave's tiles are t0 + wave, t0 + wave + 8, ...  The scan of a role partition is a few dozen tiles per wave, i.e. nothing
+    // but memory latency unless many loads are in flight: lane j of the wave fetches the descriptor (and permission window) of
+    // the wave's j-th tile -- 64 tiles per load instruction --, and the rows of DEPTH tiles are in flight while one is evaluated.
+    // Every load of the loop is issued unconditionally (masked lanes, clamped addresses), so the compiler keeps counting vmcnt.
+    constexpr int DEPTH = SCAN8_DEPTH;
+    struct Tile { uint4 x[2]; float rn[2]; };
     uint32_t round = 0;
-    for (uint32_t it = 0; it < iters; ++it) {
-        if (it + 1 < iters) fetch(t0 + (it + 1) * SCAN_WAVES + (uint32_t) wave, nxt);
-        else nxt.mask = 0;
-        if (cur.mask) {                                      // wave-uniform
+    for (uint32_t cb = 0; cb < iters; cb += 64) {
+        uint32_t d_start = 0, d_mask = 0;                    // lane j: tile cb + j of this wave
+        {
+            const uint32_t t = t0 + (cb + (uint32_t) lane) * SCAN_WAVES + (uint32_t) wave;
+            const bool have = cb + (uint32_t) lane < iters && t < t1;
+            const uint32_t tc = have ? t : t0;               // (t0 < t1: iters > 0)
+            uint2 tl;
+            if (g_tiles) tl = load_tile(g_tiles, tc);
+            else {                                           // no filter: the identity tiling of the corpus
+                tl.x = tc * RW;
+                tl.y = p.n_rows - tl.x < (uint32_t) RW ? p.n_rows - tl.x : (uint32_t) RW;
+            }
+            uint32_t mask = tl.y >= 16u ? 0xFFFFu : (1u << tl.y) - 1u;
+            if (g_bitmap) mask &= (uint32_t) bitmap_window(g_bitmap, tl.x);
+            d_start = tl.x;
+            d_mask = have ? mask : 0u;
+        }
+        const uint32_t nj = iters - cb < 64u ? iters - cb : 64u;
+        auto fetch = [&](uint32_t j, Tile& tr, uint32_t& start, uint32_t& mask) {
+            const uint32_t jc = j < nj ? j : 0u;
+            start = (uint32_t) __builtin_amdgcn_readlane((int) d_start, (int) jc);
+            mask = j < nj ? (uint32_t) __builtin_amdgcn_readlane((int) d_mask, (int) jc) : 0u;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                int dot = 0;
-                dot = __builtin_amdgcn_sdot4((int) cur.x[r].x, qv.x, dot, false);
-                dot = __builtin_amdgcn_sdot4((int) cur.x[r].y, qv.y, dot, false);
-                dot = __builtin_amdgcn_sdot4((int) cur.x[r].z, qv.z, dot, false);
-                dot = __builtin_amdgcn_sdot4((int) cur.x[r].w, qv.w, dot, false);
-                dot += __shfl_xor(dot, 1);
-                dot += __shfl_xor(dot, 2);
-                dot += __shfl_xor(dot, 4);
-                const uint32_t row = cur.start + (uint32_t) (r * 8 + g);
-                const bool ok = l == 0 && ((cur.mask >> (r * 8 + g)) & 1u);
-                const float v = fmaf(-2.0f, (float) dot, cur.rn[r] + qn);     // exact: integers below 2^24
-                const uint64_t key = make_key(v, g_rank && ok ? g_rank[row] : row);
-                const bool pass = ok && key < lds_peek(&ctrl[0].tau);
-                topk_append(keys, &ctrl[0], pass, key);
+                // a row the mask excludes reads the tile's first row instead (a line the wave fetches anyway): no branch around
+                // the load, nothing extra from HBM; its value is dropped where the mask is applied
+                const uint32_t row = start + (uint32_t) (r * 8 + g);
+                const bool ok = (mask >> (r * 8 + g)) & 1u;
+                const uint32_t rc = ok && row <= last_row ? row : (start <= last_row ? start : last_row);
+                tr.x[r] = p.scr[(size_t) rc * 8 + l];         // (kernel-argument pointers: global_load)
+                tr.rn[r] = p.norm2[rc];
+            }
+        };
+        Tile ring[DEPTH];
+        uint32_t r_start[DEPTH], r_mask[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch((uint32_t) d, ring[d], r_start[d], r_mask[d]);
+        for (uint32_t j0 = 0; j0 < nj; j0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const uint32_t j = j0 + (uint32_t) d, it = cb + j;
+                const Tile cur = ring[d];
+                const uint32_t c_start = r_start[d], c_mask = r_mask[d];
+                fetch(j + DEPTH, ring[d], r_start[d], r_mask[d]);
+                if (c_mask) {                                // wave-uniform
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        int dot = 0;
+                        dot = __builtin_amdgcn_sdot4((int) cur.x[r].x, qv.x, dot, false);
+                        dot = __builtin_amdgcn_sdot4((int) cur.x[r].y, qv.y, dot, false);
+                        dot = __builtin_amdgcn_sdot4((int) cur.x[r].z, qv.z, dot, false);
+                        dot = __builtin_amdgcn_sdot4((int) cur.x[r].w, qv.w, dot, false);
+                        dot += __shfl_xor(dot, 1);
+                        dot += __shfl_xor(dot, 2);
+                        dot += __shfl_xor(dot, 4);
+                        const uint32_t row = c_start + (uint32_t) (r * 8 + g);
+                        const bool ok = l == 0 && ((c_mask >> (r * 8 + g)) & 1u);
+                        const float v = fmaf(-2.0f, (float) dot, cur.rn[r] + qn);     // exact: integers below 2^24
+                        const uint64_t key = make_key(v, row);                       // (never a list-ordered view: the launcher checks)
+                        const bool pass = ok && key < lds_peek(&ctrl[0].tau);
+                        topk_append(keys, &ctrl[0], pass, key);
+                    }
+                }
+                if (j < nj && (it % XCHK) == XCHK - 1 && it + 1 < iters) {    // workgroup-uniform overflow vote (scan_kernel's)
+                    const bool need = lds_peek(&ctrl[0].count) > trigger;
+                    const uint32_t slot = round % 3;
+                    if (need && lane == 0) atomicOr(&flags[slot], 1u);
+                    __syncthreads();
+                    const bool any = lds_peek(&flags[slot]) != 0;
+                    if (tid == 0) flags[(round + 2) % 3] = 0;
+                    ++round;
+                    if (any && ctrl[0].count > trigger) topk_compact<SCAN_THREADS>(keys, &ctrl[0], k, tid, false);
+                }
             }
         }
-        if ((it % XCHK) == XCHK - 1 && it + 1 < iters) {      // workgroup-uniform overflow vote (scan_kernel's)
-            const bool need = lds_peek(&ctrl[0].count) > trigger;
-            const uint32_t slot = round % 3;
-            if (need && lane == 0) atomicOr(&flags[slot], 1u);
-            __syncthreads();
-            const bool any = lds_peek(&flags[slot]) != 0;
-            if (tid == 0) flags[(round + 2) % 3] = 0;
-            ++round;
-            if (any && ctrl[0].count > trigger) topk_compact<SCAN_THREADS>(keys, &ctrl[0], k, tid, false);
-        }
-        cur = nxt;
     }
     __syncthreads();
-    topk_compact<SCAN_THREADS>(keys, &ctrl[0], k, tid, false);
-    const uint32_t n = ctrl[0].count < k ? ctrl[0].count : k;
+    const uint64_t t_scan = p.fused.dbg ? wall_clock64() : 0;
+    // the k smallest, unordered, by a radix select on registers (vsr_scan.h: the merge does not need them sorted)
+    uint32_t n;
+    if (ctrl[0].count <= (uint32_t) (SCAN_THREADS * FUSED_KPT)) {
+        const uint32_t have = ctrl[0].count;
+        n = have > k ? fused_block_select<true>(keys, have, k, keys, tid) : have;
+    } else {
+        topk_compact<SCAN_THREADS>(keys, &ctrl[0], k, tid, false);
+        n = ctrl[0].count < k ? ctrl[0].count : k;
+    }
     uint64_t* dst = p.partial + (size_t) local_block * p.kp;
     for (uint32_t i = tid; i < p.kp; i += SCAN_THREADS)
         __hip_atomic_store(dst + i, i < n ? keys[i] : KEY_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (bad_query && blockIdx.x == 0 && tid == 0 && q8_bad_host) *q8_bad_host = 1u;
-    fused_tail(p, grp, local_block, keys, tid, bad_query);
+    fused_tail(p, grp, local_block, keys, tid, bad_query, t_start, t_scan, p.fused.dbg ? wall_clock64() : 0);
 }
 
 hipError_t launch_scan8_fused(const ScanParams& p, uint32_t dim, uint32_t* q8_bad_host, uint32_t n_blocks, hipStream_t s)
 {
-    if (p.rw != 16 || p.kp != p.k || !p.fused.enable || dim > 128) return hipErrorInvalidValue;
+    if (p.rw != 16 || p.kp != p.k || !p.fused.enable || dim > 128 || p.rank) return hipErrorInvalidValue;
     const size_t lds = (size_t) p.cap * 8 + sizeof(TopKCtrl) + 32 * 4 + 8 * 4 + 16;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan8_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
