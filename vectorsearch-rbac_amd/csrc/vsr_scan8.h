@@ -39,6 +39,65 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan8_fused_kernel(const Scan
     TopKCtrl* ctrl = reinterpret_cast<TopKCtrl*>(keys + cap);                 // [1]
     uint32_t* q8 = reinterpret_cast<uint32_t*>(ctrl + 1);                     // [32] the query as int8 (x - 128), 128 bytes
     uint32_t* flags = q8 + 32;                                                // [4] overflow votes, [4] = bad query, [5] = |q'|^2
+    const uint32_t trigger = cap - (uint32_t) scan_slack(RW);
+    const uint32_t iters = ((t1 - t0) + SCAN_WAVES - 1) / SCAN_WAVES;
+    const uint32_t last_row = p.n_rows - 1u;
+
+    // A wave's tiles are t0 + wave, t0 + wave + 8, ...  The scan of a role partition is a few dozen tiles per wave, i.e. nothing
+    // but memory latency unless many loads are in flight: lane j of the wave fetches the descriptor (and permission window) of
+    // the wave's j-th tile -- 64 tiles per load instruction --, and the rows of DEPTH tiles are in flight while one is evaluated.
+    // Every load of the loop is issued unconditionally (masked lanes, clamped addresses), so the compiler keeps counting vmcnt.
+    constexpr int DEPTH = SCAN8_DEPTH;
+    struct Tile { uint4 x[2]; float rn[2]; };
+    uint32_t round = 0;
+    uint32_t d_start = 0, d_mask = 0;                        // lane j: tile cb + j of this wave
+    uint32_t nj = 0;
+    auto load_desc = [&](uint32_t cb) {
+        const uint32_t t = t0 + (cb + (uint32_t) lane) * SCAN_WAVES + (uint32_t) wave;
+        const bool have = cb + (uint32_t) lane < iters && t < t1;
+        const uint32_t tc = have ? t : t0;                   // (t0 < t1 whenever there is a tile at all; else nothing is loaded)
+        uint2 tl = make_uint2(0u, 0u);
+        if (g_tiles) {
+            if (t0 < t1) tl = load_tile(g_tiles, tc);
+        } else {                                             // no filter: the identity tiling of the corpus
+            tl.x = tc * RW;
+            tl.y = p.n_rows - tl.x < (uint32_t) RW ? p.n_rows - tl.x : (uint32_t) RW;
+        }
+        uint32_t mask = tl.y >= 16u ? 0xFFFFu : (1u << tl.y) - 1u;
+        if (g_bitmap) mask &= (uint32_t) bitmap_window(g_bitmap, tl.x);
+        d_start = tl.x;
+        d_mask = have ? mask : 0u;
+        nj = iters - cb < 64u ? iters - cb : 64u;
+    };
+    auto fetch = [&](uint32_t j, Tile& tr, uint32_t& start, uint32_t& mask) {
+        const uint32_t jc = j < nj ? j : 0u;
+        start = (uint32_t) __builtin_amdgcn_readlane((int) d_start, (int) jc);
+        mask = j < nj ? (uint32_t) __builtin_amdgcn_readlane((int) d_mask, (int) jc) : 0u;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            // a row the mask excludes reads the tile's first row instead (a line the wave fetches anyway): no branch around
+            // the load, nothing extra from HBM; its value is dropped where the mask is applied
+            const uint32_t row = start + (uint32_t) (r * 8 + g);
+            const bool ok = (mask >> (r * 8 + g)) & 1u;
+            const uint32_t rc = ok && row <= last_row ? row : (start <= last_row ? start : last_row);
+            tr.x[r] = p.scr[(size_t) rc * 8 + l];         // (kernel-argument pointers: global_load)
+            tr.rn[r] = p.norm2[rc];
+        }
+    };
+    Tile ring[DEPTH];
+    uint32_t r_start[DEPTH], r_mask[DEPTH];
+    // the first descriptors and the first DEPTH tiles of rows are requested BEFORE the query is converted: the conversion (a
+    // dependent global load, two barriers) then runs under their latency instead of in front of it
+    float xs[4];                                             // the query first (every thread, clamped index: no branch), so that
+#pragma unroll                                                // its wait does not cover the row loads behind it
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t j = (uint32_t) (tid & 31) * 4 + (uint32_t) e;
+        xs[e] = p.queries[j < dim ? j : 0u];
+    }
+    load_desc(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch((uint32_t) d, ring[d], r_start[d], r_mask[d]);
+
     if (tid == 0) {
         ctrl[0].tau = KEY_EMPTY;
         ctrl[0].count = 0;
@@ -48,12 +107,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan8_fused_kernel(const Scan
     if (tid < 32) {                                          // four elements -> one word
         uint32_t word = 0, n2 = 0;
         bool bad = false;
-        float xs[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                        // four loads in flight (clamped index), one wait
-            const uint32_t j = (uint32_t) tid * 4 + (uint32_t) e;
-            xs[e] = p.queries[j < dim ? j : 0u];
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t j = (uint32_t) tid * 4 + (uint32_t) e;
@@ -74,54 +127,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan8_fused_kernel(const Scan
     const bool bad_query = lds_peek(&flags[4]) != 0;
     const float qn = (float) lds_peek(&flags[5]);
     const int4 qv = *reinterpret_cast<const int4*>(q8 + l * 4);               // this lane's 16 query elements
-    const uint32_t trigger = cap - (uint32_t) scan_slack(RW);
-    const uint32_t iters = ((t1 - t0) + SCAN_WAVES - 1) / SCAN_WAVES;
-    const uint32_t last_row = p.n_rows - 1u;
-
-    // A wave's tiles are t0 + wave, t0 + wave + 8, ...  The scan of a role partition is a few dozen tiles per wave, i.e. nothing
-    // but memory latency unless many loads are in flight: lane j of the wave fetches the descriptor (and permission window) of
-    // the wave's j-th tile -- 64 tiles per load instruction --, and the rows of DEPTH tiles are in flight while one is evaluated.
-    // Every load of the loop is issued unconditionally (masked lanes, clamped addresses), so the compiler keeps counting vmcnt.
-    constexpr int DEPTH = SCAN8_DEPTH;
-    struct Tile { uint4 x[2]; float rn[2]; };
-    uint32_t round = 0;
     for (uint32_t cb = 0; cb < iters; cb += 64) {
-        uint32_t d_start = 0, d_mask = 0;                    // lane j: tile cb + j of this wave
-        {
-            const uint32_t t = t0 + (cb + (uint32_t) lane) * SCAN_WAVES + (uint32_t) wave;
-            const bool have = cb + (uint32_t) lane < iters && t < t1;
-            const uint32_t tc = have ? t : t0;               // (t0 < t1: iters > 0)
-            uint2 tl;
-            if (g_tiles) tl = load_tile(g_tiles, tc);
-            else {                                           // no filter: the identity tiling of the corpus
-                tl.x = tc * RW;
-                tl.y = p.n_rows - tl.x < (uint32_t) RW ? p.n_rows - tl.x : (uint32_t) RW;
-            }
-            uint32_t mask = tl.y >= 16u ? 0xFFFFu : (1u << tl.y) - 1u;
-            if (g_bitmap) mask &= (uint32_t) bitmap_window(g_bitmap, tl.x);
-            d_start = tl.x;
-            d_mask = have ? mask : 0u;
+        if (cb) {
+            load_desc(cb);
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) fetch((uint32_t) d, ring[d], r_start[d], r_mask[d]);
         }
-        const uint32_t nj = iters - cb < 64u ? iters - cb : 64u;
-        auto fetch = [&](uint32_t j, Tile& tr, uint32_t& start, uint32_t& mask) {
-            const uint32_t jc = j < nj ? j : 0u;
-            start = (uint32_t) __builtin_amdgcn_readlane((int) d_start, (int) jc);
-            mask = j < nj ? (uint32_t) __builtin_amdgcn_readlane((int) d_mask, (int) jc) : 0u;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                // a row the mask excludes reads the tile's first row instead (a line the wave fetches anyway): no branch around
-                // the load, nothing extra from HBM; its value is dropped where the mask is applied
-                const uint32_t row = start + (uint32_t) (r * 8 + g);
-                const bool ok = (mask >> (r * 8 + g)) & 1u;
-                const uint32_t rc = ok && row <= last_row ? row : (start <= last_row ? start : last_row);
-                tr.x[r] = p.scr[(size_t) rc * 8 + l];         // (kernel-argument pointers: global_load)
-                tr.rn[r] = p.norm2[rc];
-            }
-        };
-        Tile ring[DEPTH];
-        uint32_t r_start[DEPTH], r_mask[DEPTH];
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) fetch((uint32_t) d, ring[d], r_start[d], r_mask[d]);
         for (uint32_t j0 = 0; j0 < nj; j0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
