@@ -103,18 +103,51 @@ __global__ __launch_bounds__(256) void km_seed_sweep_kernel(KmState k, int i)
     if (d < k.weight[j]) k.weight[j] = (float) d;
 }
 
-// ... and the weighted draw of the next centre (ivfkmeans.c:65-90): serial by definition (one thread)
-__global__ __launch_bounds__(1) void km_seed_pick_kernel(KmState k, int i)
+// ... and the weighted draw of the next centre (ivfkmeans.c:65-90): choice = sum(weight) * random, then the first sample j at
+// which choice - (weight[0] + ... + weight[j]) <= 0.  The reference walks the samples with one running double; here one
+// workgroup does it as a prefix sum: thread t adds up its contiguous chunk, the chunk sums are scanned, the thread whose chunk
+// brings the running value to <= 0 walks that chunk the reference's way.  Squared distances of integer-valued rows are
+// integers whose partial sums stay below 2^53, so every double here is exact and j is the reference's; for real-valued rows
+// the sums differ from the serial ones in their last bits and j can differ only when `choice` lies within ~1e-12 of a
+// sample's boundary.  (One thread walking 50 000 weights took 3.5 ms per centre: 3.5 s of a 4 s build with 1000 lists.)
+constexpr int KM_PICK_THREADS = 1024;
+__global__ __launch_bounds__(KM_PICK_THREADS) void km_seed_pick_kernel(KmState k, int i)
 {
-    double sum = 0.0;
-    for (int64_t j = 0; j < k.ns; ++j) sum += k.weight[j];
-    double choice = sum * km_double(k.rng);
-    int64_t j;
-    for (j = 0; j < k.ns - 1; ++j) {
-        choice -= k.weight[j];
-        if (choice <= 0) break;
+    __shared__ double s_sum[KM_PICK_THREADS];
+    __shared__ double s_choice;
+    __shared__ long long s_pick;
+    const int t = threadIdx.x;
+    const int64_t chunk = (k.ns + KM_PICK_THREADS - 1) / KM_PICK_THREADS;
+    const int64_t j0 = (int64_t) t * chunk, j1 = j0 + chunk < k.ns ? j0 + chunk : k.ns;
+    double mine = 0.0;
+    for (int64_t j = j0; j < j1; ++j) mine += k.weight[j];
+    s_sum[t] = mine;
+    if (t == 0) s_pick = -1;
+    __syncthreads();
+    for (int d = 1; d < KM_PICK_THREADS; d <<= 1) {          // inclusive scan of the chunk sums
+        const double o = t >= d ? s_sum[t - d] : 0.0;
+        __syncthreads();
+        s_sum[t] += o;
+        __syncthreads();
     }
-    for (int t = 0; t < k.dim; ++t) k.centers[(size_t) (i + 1) * k.dim + t] = k.samples[(size_t) j * k.dim + t];
+    if (t == 0) s_choice = s_sum[KM_PICK_THREADS - 1] * km_double(k.rng);
+    __syncthreads();
+    const double choice = s_choice;
+    const double before = t ? s_sum[t - 1] : 0.0;
+    // the first chunk at whose end the running value is <= 0 (exactly one thread: the predecessor's end is still > 0)
+    if (j0 < j1 && choice - s_sum[t] <= 0 && (t == 0 || choice - before > 0)) {
+        double c = choice - before;
+        int64_t j = j0;
+        for (; j < j1; ++j) {
+            c -= k.weight[j];
+            if (c <= 0) break;
+        }
+        s_pick = (long long) (j < j1 ? j : j1 - 1);
+    }
+    __syncthreads();
+    long long j = s_pick;
+    if (j < 0 || j > k.ns - 1) j = k.ns - 1;                 // the reference's loop stops at ns - 1 whatever is left of choice
+    for (int d = t; d < k.dim; d += KM_PICK_THREADS) k.centers[(size_t) (i + 1) * k.dim + d] = k.samples[(size_t) j * k.dim + d];
 }
 
 __global__ __launch_bounds__(256) void km_init_assign_kernel(KmState k)      // ivfkmeans.c:325-345
@@ -329,7 +362,7 @@ extern "C" int vsr_ivf_kmeans(vsr_ctx* ctx, int metric, int dim, const float* sa
             hipLaunchKernelGGL(km_first_center_kernel, dim3(1), dim3(1), 0, st, k);
             for (int i = 0; i < nc; ++i) {
                 hipLaunchKernelGGL(km_seed_sweep_kernel, dim3(gs), dim3(256), 0, st, k, i);
-                if (i + 1 < nc) hipLaunchKernelGGL(km_seed_pick_kernel, dim3(1), dim3(1), 0, st, k, i);
+                if (i + 1 < nc) hipLaunchKernelGGL(km_seed_pick_kernel, dim3(1), dim3(KM_PICK_THREADS), 0, st, k, i);
             }
             hipLaunchKernelGGL(km_init_assign_kernel, dim3(gs), dim3(256), 0, st, k);
             for (int iteration = 0; iteration < 500; ++iteration) {
