@@ -1040,6 +1040,10 @@ def main():
                    "sharding": f"row-range x{world}", "recall": None, "batches_in_flight": state["n_sess"]},
         "roofline": main_rec["roofline"],
         "setup_s": {"generate": round(t_gen, 1), "load": round(t_load, 1)},
+        # what this rank keeps in HBM for the corpus: the fp32 rows (exact re-rank, K1), the hi-only bf16 screening planes and,
+        # for u8-valued rows, the int8 planes the headline kernel reads; side arrays = ids, norms, document index
+        "resident_bytes": {"fp32_rows": int(hi - lo) * dim * 4, "bf16_hi_planes": int(hi - lo) * dim * 2,
+                           "int8_planes": int(hi - lo) * (dim + 4), "side_arrays": int(hi - lo) * 32},
         "host_enqueue_ms_per_step": main_rec["host_enqueue_ms_per_step"],
         "host_busy_ms_per_step": main_rec["host_busy_ms_per_step"],
         "host_library_ms_per_step": main_rec["host_library_ms_per_step"],
@@ -1310,8 +1314,8 @@ def main():
                                      "serial (rehearsal through host memory)" if rehearsal else "serial, one per batch")
     if sim_world > 1:
         out["sim_world"] = {"parts": parts, "merged_equals_local": bool(all(r["sim_ok"] for r in results.values()))}
-    if rank == 0 and world > 1 and os.environ.get("VSR_BENCH_VERIFY") == "1":
-        # rehearsal check: the merged multi-rank result of a few queries against the oracle on the full corpus
+    if rank == 0 and world > 1 and os.environ.get("VSR_BENCH_VERIFY", "1") != "0":
+        # default on: the merged multi-rank result of a few queries against the oracle on the full corpus (rank 0 regenerates it)
         from oracle.oracle import Oracle
         orc = Oracle("pgflags")
         xf, blkf, docf = sift_like_corpus(n, dim, seed=args.seed)
