@@ -423,6 +423,23 @@ def place_roles(parent, weights, n_bins):
     return where, load
 
 
+def draw_rank_queries(sample_queries, where, role_of, me, nq, n, seed, mult, count, seed0):
+    """`count` steps' queries of rank `me` under role placement: a step is mult x nq queries drawn exactly like the N = 1
+    step's (mult draws of nq, consecutive seeds); the rank keeps those whose user's role it hosts.  mult = N: weak scaling
+    (about nq per rank and step); mult = 1: strong scaling (the N = 1 step spread over the ranks).  Every query of a step
+    belongs to exactly one rank."""
+    made = []
+    for b in range(count):
+        qr, qu = [], []
+        for j in range(mult):
+            qrow, quser = sample_queries(nq, n, 1000, seed=seed + 1000 * (seed0 + b * mult + j))
+            mine = np.flatnonzero(np.array([where[role_of[int(u)]] == me for u in quser]))
+            qr.append(qrow[mine])
+            qu.append(quser[mine])
+        made.append((np.concatenate(qr), np.concatenate(qu)))
+    return made
+
+
 def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim_world, rehearsal):
     """N > 1, role-partition placement (controller/dynamic_partition/search.py:54-58 searches exactly the
     partition tables of a user's role combination): every ROLE lives on one GPU together with everything it can see (its
@@ -454,17 +471,7 @@ def placement_bench(args, torch, dist, vsrbac, rank, local_rank, world, dev, sim
     weak = args.scaling == "weak" and parts > 1
 
     def draw(mult, count, seed0):
-        """`count` batches of mult x nq queries drawn like the N = 1 step's; this rank keeps those of its roles."""
-        made = []
-        for b in range(count):
-            qr, qu = [], []
-            for j in range(mult):
-                qrow, quser = sample_queries(nq, n, 1000, seed=args.seed + 1000 * (seed0 + b * mult + j))
-                mine = np.flatnonzero(np.array([where[role_of[int(u)]] == me for u in quser]))
-                qr.append(qrow[mine])
-                qu.append(quser[mine])
-            made.append((np.concatenate(qr), np.concatenate(qu)))
-        return made
+        return draw_rank_queries(sample_queries, where, role_of, me, nq, n, args.seed, mult, count, seed0)
 
     # weak scaling (the default for N > 1): a step is N x 1000 queries, so every rank answers about 1000 -- the N = 1 step's
     # work per GPU; strong scaling (--scaling strong, and the sibling record of a weak run): the same 1000-query step as N = 1

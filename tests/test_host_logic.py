@@ -212,3 +212,12 @@ def test_role_placement_covers_every_query_exactly_once():
                 assert np.isin(rbac.visible_docs(int(u)), docs).all()
         assert (seen == 1).all()
         assert total_rows < 1.3 * n                                          # replication of the classes near the root stays modest
+        # the steps of the two scaling modes: weak = N x 1000 queries per step (about 1000 per rank), strong = the N = 1 step's
+        # 1000 spread over the ranks; either way the ranks' shares partition the step
+        for mult in (parts, 1):
+            per_rank = [bench.draw_rank_queries(sample_queries, where, role_of, g, 1000, n, 20251121, mult, 2, 0) for g in range(parts)]
+            for b in range(2):
+                assert sum(len(per_rank[g][b][0]) for g in range(parts)) == 1000 * mult
+                if mult == parts:
+                    assert all(800 < len(per_rank[g][b][0]) < 1250 for g in range(parts))
+            assert all(where[role_of[int(u)]] == g for g in range(parts) for u in per_rank[g][0][1])
