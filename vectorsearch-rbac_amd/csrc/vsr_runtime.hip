@@ -167,6 +167,8 @@ struct vsr_ctx {
     // knobs
     int block_budget = 0;          // 0 = 4 * CUs
     bool fused_dbg = false;        // VSR_FUSED_DBG=1
+    bool scan_lane = false;        // VSR_SCAN_LANE=1
+    hipEvent_t lane_in = nullptr, lane_out = nullptr;
     int fused_fan = 0;             // VSR_FUSED_FAN: lists per first-level merge of the one-query launch (0: the planner's rule)
     int min_rows_per_block = 256;
     int min_shared_rows = 2048;    // rows per workgroup of a shared pass (VSR_MIN_SHARED_ROWS)
@@ -203,6 +205,8 @@ struct vsr_ctx {
         // (every DevBuf / PinBuf member releases itself: ~DevBuf, ~PinBuf)
         if (desc_done) (void) hipEventDestroy(desc_done);
         if (d_flag_total) (void) hipFree(d_flag_total);
+        if (lane_in) (void) hipEventDestroy(lane_in);
+        if (lane_out) (void) hipEventDestroy(lane_out);
         if (own_stream) (void) hipStreamDestroy(own_stream);
     }
 };
@@ -233,6 +237,9 @@ struct vsr_filter {
 
 struct vsr_corpus {
     vsr_ctx*    ctx = nullptr;
+    // the corpus's scan lane (VSR_SCAN_LANE=1): the main scan launches of ALL sessions over this corpus queue up on this one
+    // stream, so two of them never share the GPU (their short kernels still run beside the other sessions' scans)
+    mutable hipStream_t scan_stream = nullptr;
     int64_t     n = 0;
     int         dim = 0;
     uint32_t    stride4 = 0;
@@ -332,6 +339,7 @@ extern "C" int vsr_open(int device, vsr_ctx** out)
     const char* env;
     if ((env = getenv("VSR_BLOCK_BUDGET"))) ctx->block_budget = atoi(env);
     if ((env = getenv("VSR_FUSED_FAN"))) ctx->fused_fan = atoi(env);
+    if ((env = getenv("VSR_SCAN_LANE"))) ctx->scan_lane = atoi(env) != 0;
     if ((env = getenv("VSR_FUSED_DBG"))) ctx->fused_dbg = atoi(env) != 0;
     if ((env = getenv("VSR_MIN_ROWS_PER_BLOCK"))) ctx->min_rows_per_block = std::max(1, atoi(env));
     if ((env = getenv("VSR_MAX_QB"))) { ctx->max_qb = std::max(1, atoi(env)); ctx->max_qb_set = true; }
@@ -499,6 +507,7 @@ extern "C" int vsr_corpus_free(vsr_corpus* c)
 
 vsr_corpus::~vsr_corpus()
 {
+    if (scan_stream) { (void) hipStreamSynchronize(scan_stream); (void) hipStreamDestroy(scan_stream); }
     drop_cached_filters(this);
     void* ptrs[] = {d_rows, d_scr, d_scr_c, d_scr8, d_norm2_8, d_all_tiles, d_doc_class, d_rank, d_norm2, d_norm2_max, d_block, d_doc, d_orig, d_row_docidx, d_doc_mask};
     for (void* p : ptrs)
@@ -1805,7 +1814,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.q_scr_c = reinterpret_cast<const uint4*>(ds + off_qc);
         sp.cstride4 = c->cstride4;
     }
-    auto launch_pass = [&](uint32_t blocks) { return plan.k2g ? launch_gemm(sp, metric, blocks, ctx->stream) : launch_mfmaw(sp, metric, blocks, ctx->stream); };
+    auto launch_pass = [&](uint32_t blocks, hipStream_t st) { return plan.k2g ? launch_gemm(sp, metric, blocks, st) : launch_mfmaw(sp, metric, blocks, st); };
     sp.q_slots = reinterpret_cast<const uint32_t*>(ds + off_qs);
     sp.kp = sp.k = kp;
     sp.qmax = plan.qmax;
@@ -1830,7 +1839,7 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.qcnt = scnt;
         sp.capq = GQ_SAMPLE_CAP;
         sp.k2i = plan.k2i_sample ? 2u : 0u;                 // (bit 1: the sample launch on K2i; bit 0: the main launch)
-        HIPCHK(launch_pass(plan.n_blocks_s));
+        HIPCHK(launch_pass(plan.n_blocks_s, ctx->stream));
         HIPCHK(launch_seed_select(ctx->d_samp.as<uint64_t>(), scnt, GQ_SAMPLE_CAP, plan.kp_frac, ctx->d_tau.as<uint64_t>(),
                                   (uint32_t) nq, ctx->stream));
         if (a0) {
@@ -1838,11 +1847,22 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
             ctx->pending.push_back({a0, a1, 3});
         }
         // ---- main pass ----
+        hipStream_t main_stream = ctx->stream;
+        if (ctx->scan_lane) {                               // the main launch goes to the corpus's lane, behind this batch's seeds
+            if (!c->scan_stream) HIPCHK(hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking));
+            if (!ctx->lane_in) {
+                HIPCHK(hipEventCreateWithFlags(&ctx->lane_in, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ctx->lane_out, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(ctx->lane_in, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(c->scan_stream, ctx->lane_in, 0));
+            main_stream = c->scan_stream;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->profiling) {
             e0 = take_event(ctx);
             e1 = take_event(ctx);
-            HIPCHK(hipEventRecord(e0, ctx->stream));
+            HIPCHK(hipEventRecord(e0, main_stream));
         }
         sp.groups = reinterpret_cast<const ScanGroup*>(ds + off_g);
         sp.n_groups = (uint32_t) plan.groups.size();
@@ -1863,10 +1883,14 @@ static int search_wide(vsr_ctx* ctx, vsr_corpus* c, const Plan& plan, const floa
         sp.qcnt = qcnt;
         sp.capq = GQ_CAP;
         if (!plan.block_map.empty() && !ctx->no_xcd_map) sp.block_map = reinterpret_cast<const uint2*>(ds + off_bm);
-        HIPCHK(launch_pass(sp.block_map ? plan.n_launch : plan.n_blocks));
+        HIPCHK(launch_pass(sp.block_map ? plan.n_launch : plan.n_blocks, main_stream));
         if (e0) {
-            HIPCHK(hipEventRecord(e1, ctx->stream));
+            HIPCHK(hipEventRecord(e1, main_stream));
             ctx->pending.push_back({e0, e1, 1});
+        }
+        if (ctx->scan_lane) {                               // the selection waits for the lane
+            HIPCHK(hipEventRecord(ctx->lane_out, main_stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_out, 0));
         }
         ctx->last_kernel = scan_kernel_name(plan, c, metric, ctx->last_k2i);
         ctx->stats.scan_bytes[1] += plan.scan_bytes;
