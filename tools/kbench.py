@@ -90,7 +90,8 @@ def main():
                 st = ctx.stats()
                 ctx.profiling(False)
                 rec = {"case": case, "budget": budget, "minrows": minrows, "wall_ms": round(wall * 1e3, 4),
-                       "qps": round(nq / wall, 1), "select_ms": round(st["select_ms"] / args.steps, 4)}
+                       "qps": round(nq / wall, 1), "select_ms": round(st["select_ms"] / args.steps, 4),
+                       "kernel": ctx.last_scan_kernel(), "flagged": ctx.screening_check(0)[0]}
                 for c in (0, 1):
                     if st["scan_launches"][c]:
                         ms = st["scan_ms"][c] / st["scan_launches"][c]
