@@ -764,6 +764,35 @@ def test_one_query_per_call_on_int8_planes(ctx, oracle):
         corpus.free()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_one_query_per_call_randomized(ctx, oracle, seed):
+    """nq == 1, random shapes: the in-kernel merge's radix selects (per-workgroup top-k, two merge levels, rank placement of
+    the final order) on corpora from a few dozen rows to 150 k, tie-saturated or plain, u8-valued (scan8 on the int8 planes)
+    or not (K1 on the fp32 rows), ranges / bitmaps / no filter, k from 1 to 400, ragged documents."""
+    import vsrbac
+    rng = np.random.default_rng(4242 + seed)
+    n = int(rng.choice([40, 700, 5_000, 40_000, 150_000]))
+    dim = int(rng.choice([8, 32, 96, 128]))
+    if rng.random() < 0.5:
+        base = sift_like(rng, max(8, n // int(rng.choice([1, 50, 400]))), dim)     # every vector up to ~400 times: ties
+        x = base[rng.integers(0, len(base), n)]
+    else:
+        x = sift_like(rng, n, dim)
+    if seed % 4 == 3:
+        x = x + np.float32(0.5)                                                     # not u8-valued: the fp32 rows
+    blk, doc = _ids(n, int(rng.choice([1, 7, 37, 100])))
+    corpus = ctx.load_corpus(x, blk, doc)
+    mask = (rng.random(int(doc.max()) + 1) < rng.choice([0.05, 0.4, 0.95]))[doc].astype(np.uint8)
+    for mode in (vsrbac.RANGES, vsrbac.BITMAP, None):
+        f = None if mode is None else corpus.filter_from_bytemask(mask, mode)
+        for k in sorted({1, int(rng.integers(2, 40)), int(rng.integers(40, 400))}):
+            q = x[rng.integers(0, n)].copy()
+            for metric in (("l2", "ip") if k < 40 and seed % 4 != 3 else ("l2",)):       # (x + 0.5: only the L2 sums stay exact)
+                res = corpus.search(q[None, :], k, metric, None if f is None else [f])
+                _expect_exact(oracle, res, 0, metric, x, q, k, doc, blk, None if f is None else mask)
+    corpus.free()
+
+
 def test_int8_planes_for_sift_like_queries(ctx, oracle):
     """A corpus of integers 0..255 (d <= 128) keeps int8 planes; L2 searches whose queries are such integers screen on
     them (v_mfma_i32_16x16x64_i8, exact).  Host queries are checked by the library; device-resident queries only under
