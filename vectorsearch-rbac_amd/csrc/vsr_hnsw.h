@@ -169,13 +169,25 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const HnswParams p)
         const uint32_t pos = lo;
         if (pos >= p.caps) return;
         const uint32_t last = count < p.caps ? count : p.caps - 1;      // index the shifted tail ends at
-        for (int64_t base = (int64_t) ((last - 1) & ~63u); last > pos && base >= (int64_t) (pos & ~63u); base -= 64) {   // from the end
-            const uint32_t i = (uint32_t) base + (uint32_t) lane;
-            const bool mv = i >= pos && i < last;
-            const uint64_t kk = mv ? S[i] : 0;
-            const uint8_t xx = mv ? X[i] : 0;
+        // the tail [pos, last) moves up by one, 256 entries per step from the end (four per lane: a step is two wave barriers
+        // whatever it moves, and at ef_search in the thousands the tail is a thousand entries long)
+        for (int64_t base = (int64_t) ((last - 1) & ~255u); last > pos && base >= (int64_t) (pos & ~255u); base -= 256) {
+            const uint32_t i0 = (uint32_t) base + 4u * (uint32_t) lane;
+            uint64_t kk[4];
+            uint8_t xx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + (uint32_t) u;
+                const bool mv = i >= pos && i < last;
+                kk[u] = mv ? S[i] : 0;
+                xx[u] = mv ? X[i] : 0;
+            }
             wave_sync();
-            if (mv) { S[i + 1] = kk; X[i + 1] = xx; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + (uint32_t) u;
+                if (i >= pos && i < last) { S[i + 1] = kk[u]; X[i + 1] = xx[u]; }
+            }
             wave_sync();
         }
         if (lane == 0) { S[pos] = key; X[pos] = 0; }
