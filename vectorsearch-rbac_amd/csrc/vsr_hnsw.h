@@ -161,12 +161,26 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const HnswParams p)
     uint32_t first_open = 0;                 // every entry before this position is expanded
     // insert (key, unexpanded) into S keeping it sorted; beyond caps the largest entry falls off
     auto insert = [&](uint64_t key) {
-        uint32_t lo = 0, hi = count;         // position = number of keys < key (wave-uniform binary search: S is sorted)
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (S[mid] < key) lo = mid + 1; else hi = mid;
+        // position = number of keys < key.  A binary search is a chain of log2(count) dependent LDS reads (eleven at ef_search
+        // in the thousands: over a microsecond per insert); the wave does a 64-ary search instead: lane l compares the LAST key of
+        // segment l (count / 64 keys, rounded up), the segments entirely below the key are a prefix, and the one segment that is
+        // left is compared key by key -- two or three LDS round trips whatever the count.
+        uint32_t pos = 0;
+        if (count) {
+            const uint32_t seg_len = (count + 63u) / 64u;
+            const uint32_t s0 = (uint32_t) lane * seg_len;
+            const uint32_t s1 = s0 + seg_len < count ? s0 + seg_len : count;
+            const bool has = s0 < count;
+            const uint64_t pivot = has ? S[s1 - 1] : KEY_EMPTY;
+            const uint32_t seg = (uint32_t) __popcll(__ballot(has && pivot < key));      // segments whose every key is < key
+            const uint32_t b0 = seg * seg_len;
+            const uint32_t b1 = b0 + seg_len < count ? b0 + seg_len : count;
+            pos = b0 < count ? b0 : count;
+            for (uint32_t o = b0; o < b1; o += 64) {
+                const uint32_t i = o + (uint32_t) lane;
+                pos += (uint32_t) __popcll(__ballot(i < b1 && S[i] < key));
+            }
         }
-        const uint32_t pos = lo;
         if (pos >= p.caps) return;
         const uint32_t last = count < p.caps ? count : p.caps - 1;      // index the shifted tail ends at
         // the tail [pos, last) moves up by one, 256 entries per step from the end (four per lane: a step is two wave barriers
