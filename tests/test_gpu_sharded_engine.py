@@ -76,3 +76,69 @@ def test_two_ranks_on_one_gpu_with_flagged_redo(oracle, tmp_path):
         np.testing.assert_array_equal(got["blk"][i, :m], blk[idx])
         np.testing.assert_array_equal(got["doc"][i, :m], doc[idx])
         np.testing.assert_array_equal(got["dist"][i, :m], dist.astype(np.float32))
+
+
+def test_index_scans_shard_like_exact_scans(ctx_free_gpu, oracle):
+    """Per-shard IVFFlat / HNSW indexes behind ShardedSearcher (the reference's one index per partition table + client-side
+    merge): two shards on one GPU, the all-gather emulated by concatenating the ranks' packed records.  IVFFlat with
+    probes = lists is exhaustive: the merged result equals the oracle's exact filtered top-k.  HNSW: the merged list equals
+    the k best of what the two shard graphs return on their own (distance, then global row)."""
+    import torch
+    import vsrbac
+    from vsrbac.sharded import GpuShardEngine, ShardedSearcher, shard_bounds
+    rng = np.random.default_rng(31)
+    n, dim, k, nq = 24_000, 64, 20, 12
+    x = np.clip(np.rint(np.abs(rng.normal(0, 45, (n, dim)))), 0, 255).astype(np.float32)
+    blk = (np.arange(n) + 1).astype(np.int64)
+    doc = (np.arange(n) // 10 + 1).astype(np.int32)
+    mask = (rng.random(int(doc.max()) + 1) < 0.5)[doc].astype(np.uint8)
+    q = x[rng.integers(0, n, nq)] + rng.integers(0, 2, (nq, dim)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    engines, packs, per_shard = [], [], []
+    for r in range(2):
+        lo, hi = shard_bounds(n, 2, r, align=10)
+        c = vsrbac.Context(0)
+        corpus = c.load_corpus(x[lo:hi], blk[lo:hi], doc[lo:hi], row_offset=lo)
+        e = GpuShardEngine(c, corpus, dev)
+        ivf, _, _ = corpus.build_ivf(x[lo:hi], 16, "l2", seed=3)
+        e.attach_index("ivf", ivf)
+        e.attach_index("hnsw", corpus.build_hnsw(8, 32, "l2", seed=5))
+        e.filters = [corpus.filter_from_bytemask(mask[lo:hi], vsrbac.BITMAP)] * nq
+        engines.append((e, c, corpus, lo))
+    for kind, params in (("ivf", {"probes": 16}), ("hnsw", {"ef_search": 64})):
+        locs = [e.search_local_index(kind, q, k, "l2", e.filters, **params) for e, _, _, _ in engines]
+        torch.cuda.synchronize()
+        g = torch.cat([l["pack"] for l in locs])
+        b, d, dd, cnt = engines[0][0].merge_packed(g, nq, k)
+        torch.cuda.synchronize()
+        b, dd, cnt = b.cpu().numpy(), dd.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(nq):
+            if kind == "ivf":                                       # exhaustive probe: the exact answer
+                idx, dist = oracle.filtered_topk("l2", x, q[i], k, doc, blk, mask)
+                assert cnt[i] == idx.size
+                np.testing.assert_array_equal(b[i, :cnt[i]], blk[idx])
+                np.testing.assert_array_equal(dd[i, :cnt[i]], dist.astype(np.float32))
+            else:                                                   # the k best of the two graphs' own answers
+                cand = []
+                for (e, c, corpus, lo) in engines:
+                    res, _ = e.indexes["hnsw"].search(q[i][None, :], k, 64, "l2", [e.filters[i]])
+                    cand += [(float(res.dist[0, j]), int(res.rows[0, j]) + lo, int(res.block_ids[0, j])) for j in range(int(res.counts[0]))]
+                cand.sort()
+                want = cand[:k]
+                assert cnt[i] == len(want)
+                np.testing.assert_array_equal(b[i, :cnt[i]], np.array([w[2] for w in want], dtype=np.int64))
+                assert (np.diff(dd[i, :cnt[i]]) >= 0).all()
+    # the collective path of ShardedSearcher with world = 1 takes the same entry point
+    s1 = ShardedSearcher(engines[0][0], 1, 0, None)
+    b1, d1, dd1, c1 = s1.search(q, k, "l2", engines[0][0].filters, index="ivf", probes=16)
+    assert int(c1.cpu()[0]) > 0
+    for e, c, corpus, lo in engines:
+        for ix in e.indexes.values():
+            ix.free()
+        corpus.free()
+        c.close()
+
+
+@pytest.fixture
+def ctx_free_gpu():
+    yield None

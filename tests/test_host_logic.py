@@ -221,3 +221,20 @@ def test_role_placement_covers_every_query_exactly_once():
                 if mult == parts:
                     assert all(800 < len(per_rank[g][b][0]) < 1250 for g in range(parts))
             assert all(where[role_of[int(u)]] == g for g in range(parts) for u in per_rank[g][0][1])
+
+
+def test_device_keys_of_index_results_match_the_library_key():
+    """GpuShardEngine.device_keys (torch, used to merge per-shard index results) builds the library's ordering key:
+    identical to sharded.monotone_keys for finite values, -0 == +0, NaN last among values, empty slots last of all."""
+    import types
+    import torch
+    from vsrbac.sharded import GpuShardEngine, monotone_keys
+    dist = np.array([0.0, -0.0, 1.5, -2.25, np.inf, -np.inf, np.nan, 3.0e38, 1e-40], dtype=np.float32)
+    rows = np.arange(dist.size, dtype=np.int64) + 5
+    got = GpuShardEngine.device_keys(types.SimpleNamespace(torch=torch), torch.from_numpy(dist), torch.from_numpy(rows), 1000)
+    want = monotone_keys(dist, rows + 1000)
+    np.testing.assert_array_equal(got.numpy().view(np.uint64), want)
+    empty = GpuShardEngine.device_keys(types.SimpleNamespace(torch=torch), torch.tensor([np.inf]), torch.tensor([-1]), 7)
+    assert int(empty.numpy().view(np.uint64)[0]) == 0xFFFFFFFFFFFFFFFF
+    order = np.argsort(got.numpy().view(np.uint64))
+    assert list(dist[order][:2]) == [-np.inf, -2.25] and np.isnan(dist[order][-1])

@@ -216,6 +216,7 @@ class Corpus:
                                         C.byref(h)))
         self._h = h
         self.n, self.dim = n, dim
+        self.row_offset = int(row_offset)
         self._user_filters = {}
 
     def free(self):

@@ -7,6 +7,12 @@ controller/baseline/prefilter/prefilter_role.py:174-189).  Here every rank owns 
 (k * 24 bytes per query) are exchanged with ONE all-gather per query batch over RCCL/xGMI and merged on the GPU
 (vsr_merge_topk_device).  Ordering keys carry the global row, so the merged order equals the single-GPU order.
 
+Index scans shard the same way (the reference's analogue: one hnsw / ivfflat index per partition table, searched one after
+another and merged by the client, controller/dynamic_partition/search.py:54-58,347-364): every rank builds or loads an
+index over ITS rows (`GpuShardEngine.attach_index`), `ShardedSearcher.search(..., index=...)` probes every rank's index
+with the same parameters (ef_search / probes) and merges the per-rank lists with the same packed all-gather and merge
+launch; the ordering key of an index result is (monotone bits of the returned distance << 32) | global row.
+
 `ShardedSearcher` holds the rank arithmetic and the collective plumbing; the per-shard compute is an `engine`
 object (GpuShardEngine in production).  Tests drive the same class under gloo with a CPU stand-in engine.
 """
@@ -40,9 +46,14 @@ class ShardedSearcher:
     def __init__(self, engine, world=1, rank=0, dist=None, group=None):
         self.engine, self.world, self.rank, self.dist, self.group = engine, world, rank, dist, group
 
-    def search(self, queries, k, metric="l2", filters=None):
-        """Every rank passes the same queries; returns (block_ids, doc_ids, dist, counts) of the global top-k."""
-        local = self.engine.search_local(queries, k, metric, filters)      # dict of [nq, k] tensors
+    def search(self, queries, k, metric="l2", filters=None, index=None, **index_params):
+        """Every rank passes the same queries; returns (block_ids, doc_ids, dist, counts) of the global top-k.
+        index = "ivf" / "hnsw": every rank scans its attached index (index_params: probes=... / ef_search=...) instead of
+        its rows, and the merged list is the k best of what the ranks' indexes returned."""
+        if index is None:
+            local = self.engine.search_local(queries, k, metric, filters)  # dict of [nq, k] tensors
+        else:
+            local = self.engine.search_local_index(index, queries, k, metric, filters, **index_params)
         if self.world == 1:
             return self.engine.finalize(local)
         import torch
@@ -101,6 +112,56 @@ class GpuShardEngine:
 
     def finalize(self, local):
         return local["block"], local["doc"], local["dist"], local["counts"]
+
+    # ---- index scans over this rank's rows ---------------------------------------------------------
+    def attach_index(self, kind, index):
+        """kind: "ivf" (vsrbac.IvfIndex) or "hnsw" (vsrbac.HnswIndex) over this rank's corpus."""
+        if kind not in ("ivf", "hnsw"):
+            raise ValueError("index kind must be 'ivf' or 'hnsw'")
+        if not hasattr(self, "indexes"):
+            self.indexes = {}
+        self.indexes[kind] = index
+
+    def device_keys(self, dist, rows, row_offset):
+        """The library's ordering key on the device: (monotone fp32 bits << 32) | global row; empty slots (row < 0) sort last."""
+        torch = self.torch
+        v = dist.to(torch.float32) + 0.0
+        u = v.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        u = torch.where(torch.isnan(v), torch.full_like(u, 0x7FC00000), u)
+        neg = (u & 0x80000000) != 0
+        m = torch.where(neg, (~u) & 0xFFFFFFFF, u | 0x80000000)
+        keys = (m << 32) | ((rows + int(row_offset)) & 0xFFFFFFFF)
+        return torch.where(rows < 0, torch.full_like(keys, -1), keys)      # (-1 = 0xFFFF...: KEY_EMPTY)
+
+    def search_local_index(self, kind, queries, k, metric, filters, probes=None, ef_search=None):
+        torch = self.torch
+        index = getattr(self, "indexes", {}).get(kind)
+        if index is None:
+            raise ValueError(f"no {kind} index attached to this rank (attach_index)")
+        q = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries, np.float32))
+        q = q.to(self.device, torch.float32).contiguous()
+        nq = q.shape[0]
+        nk = nq * k
+        pack = torch.empty((self.ctx.packed_result_bytes(nq, k),), dtype=torch.uint8, device=self.device)
+        out = {"keys": pack[0:nk * 8].view(torch.int64).view(nq, k),
+               "block": pack[nk * 8:nk * 16].view(torch.int64).view(nq, k),
+               "doc": pack[nk * 16:nk * 20].view(torch.int32).view(nq, k),
+               "dist": pack[nk * 20:nk * 24].view(torch.float32).view(nq, k),
+               "counts": torch.empty((nq,), dtype=torch.int32, device=self.device)}
+        rows = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        ptrs = (self._p(out["block"]), self._p(out["doc"]), self._p(rows), self._p(out["dist"]), self._p(out["counts"]))
+        if kind == "ivf":
+            index.search_device(self._p(q), nq, k, int(probes if probes is not None else 1), metric, filters, *ptrs)
+        else:
+            keep = index.search_device(self._p(q), nq, k, int(ef_search if ef_search is not None else 40), metric, filters, *ptrs)
+            self.ctx.synchronize()                          # (one asynchronous launch: the filter array must outlive it)
+            del keep
+        # slots past a query's count hold -1 / +inf already (the ABI's convention); their keys sort last
+        valid = torch.arange(k, device=self.device)[None, :] < out["counts"][:, None]
+        rows = torch.where(valid, rows, torch.full_like(rows, -1))
+        out["keys"].copy_(self.device_keys(out["dist"], rows, self.corpus.row_offset))
+        out["pack"] = pack
+        return out
 
     def merge_packed(self, g_pack, nq, k):
         torch = self.torch
