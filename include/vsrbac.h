@@ -255,6 +255,13 @@ int vsr_hnsw_search(vsr_hnsw* index, const float* queries, int nq, int dim, int 
  * into one element (hnswbuild.c:329-351): every row is its own element.  Synchronises. */
 int vsr_hnsw_build(vsr_corpus* corpus, int m, int ef_construction, int metric, uint64_t seed, vsr_hnsw** out);
 int vsr_hnsw_info(const vsr_hnsw* index, int32_t* n_elem, int32_t* entry, int32_t* entry_level, int32_t* max_level);
+/* Predicate-aware walk (off by default: pgvector filters what the index returns, hnswscan.c + the executor's RLS qual).  On:
+ * the layer-0 search of later vsr_hnsw_search* calls applies the query's filter while it walks, ACORN-1 style -- the result
+ * set and the candidate set hold permitted elements only, and an expansion also takes the permitted neighbours of its
+ * neighbours that are not permitted -- which is what acorn_benchmark/src/acorn_search.cpp:144-181 gets from the ACORN
+ * library (its source is not part of the reference tree: parity is with the index oracle's restatement of this walk and
+ * with the exact filtered scan by recall).  Queries without a filter are searched as before. */
+int vsr_hnsw_set_predicate_aware(vsr_hnsw* index, int on);
 int vsr_hnsw_search_device(vsr_hnsw* index, const float* d_queries, int nq, int dim, int k, int ef_search, int metric,
                            const vsr_filter* const* filters,
                            int64_t* d_out_block_ids, int32_t* d_out_doc_ids, int64_t* d_out_rows, float* d_out_dist,

@@ -24,8 +24,15 @@ _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
     targets = ["liboracle.so", "liboracle_pgflags.so"]
-    if force or not all(os.path.exists(os.path.join(_HERE, t)) for t in targets):
-        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    have = all(os.path.exists(os.path.join(_HERE, t)) for t in targets)
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
+    else:
+        # make decides (the libraries depend on the sources): a stale library must never check a newer header's functions;
+        # where no compiler is at hand the prebuilt libraries are used as they are
+        rc = subprocess.call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL if have else None)
+        if rc != 0 and not have:
+            raise RuntimeError("oracle: make failed and no prebuilt library is present")
     if os.path.isdir("/root/reference"):
         # optional reference-derived secondary oracle (vendored hnswlib, compiled in place)
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL,
@@ -64,6 +71,7 @@ def _bind(lib):
         "orc_hnsw_info": (None, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "orc_hnsw_export": (None, [vp, _i32p, _i32p, _i32p, _i64p, _i32p, _i32p, C.c_int32]),
         "orc_hnsw_search": (i64, [vp, _f32p, i, _i64p, _f64p, _i32p, C.POINTER(i64)]),
+        "orc_hnsw_search_pa": (i64, [vp, _f32p, i, _u8p, _i64p, _f64p, _i32p, C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -271,6 +279,18 @@ class HnswIndex:
         elems = np.zeros(ef + 2, dtype=np.int32)
         nv = C.c_int64()
         n = self.orc.lib.orc_hnsw_search(self._h, q, int(ef), rows, dist, elems, C.byref(nv))
+        return rows[:n], dist[:n], elems, nv.value
+
+    def search_predicate_aware(self, q, ef, allowed_rows):
+        """The predicate-aware layer-0 walk (vsr_index_oracle.c: search_layer_pa): rows (unfiltered: apply allowed_rows),
+        index distances, elements, marked-element count."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        al = np.ascontiguousarray(allowed_rows, dtype=np.uint8)
+        rows = np.zeros(ef * 10 + 10, dtype=np.int64)
+        dist = np.zeros(ef * 10 + 10, dtype=np.float64)
+        elems = np.zeros(ef + 2, dtype=np.int32)
+        nv = C.c_int64()
+        n = self.orc.lib.orc_hnsw_search_pa(self._h, q, int(ef), al, rows, dist, elems, C.byref(nv))
         return rows[:n], dist[:n], elems, nv.value
 
     def export(self):

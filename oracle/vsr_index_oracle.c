@@ -344,6 +344,86 @@ static int search_layer(const orc_hnsw *g, const float *q, const scand *ep, int 
     return nw;
 }
 
+/* The predicate-aware layer-0 walk of the GPU's K4 (vsr_hnsw.h, predicate_aware; ACORN-1 style -- the ACORN library the
+ * reference calls at acorn_benchmark/src/acorn_search.cpp:144-181 is not part of the reference tree, so this restates OUR walk;
+ * parity unpinned against ACORN itself).  Like search_layer on layer 0, except that an expansion of c takes, in list order,
+ * c's unvisited neighbours that are allowed, then for every unvisited neighbour that is NOT allowed (marked visited too) its
+ * allowed unvisited neighbours, 64 list positions at a time, until 256 candidates are collected (what a 64-position step marks
+ * beyond the cap stays marked and is dropped).  allowed_rows: one byte per heap row; an element is allowed when one of its
+ * heap rows is.  n_visited counts every element marked. */
+#define ORC_PA_CAP 256
+static int elem_allowed(const orc_hnsw *g, int32_t e, const uint8_t *allowed_rows)
+{
+    for (int t = 0; t < g->tid_count[e]; t++)
+        if (allowed_rows[g->tids[e][t]]) return 1;
+    return 0;
+}
+
+static int search_layer_pa(const orc_hnsw *g, const float *q, const scand *ep, int n_ep, int ef, scand *w, uint8_t *visited,
+                           int64_t *n_visited, const uint8_t *allowed_rows)
+{
+    sheap C = {0}, W = {0};
+    W.maxheap = 1;
+    int wlen = 0;
+    const int lm = layer_m(g->m, 0);
+    int32_t cand[ORC_PA_CAP];
+    int32_t *hop = (int32_t *) malloc(sizeof(int32_t) * (size_t) (lm + 1));
+    memset(visited, 0, (size_t) g->n_elem);
+    for (int i = 0; i < n_ep; i++) {
+        visited[ep[i].elem] = 1;
+        if (n_visited) (*n_visited)++;
+        sheap_push(&C, ep[i]);
+        sheap_push(&W, ep[i]);
+        wlen++;
+    }
+    while (C.n > 0) {
+        scand c = sheap_pop(&C);
+        scand f = W.a[0];
+        if (c.dist > f.dist) break;
+        int32_t *len;
+        hcand *nb = nbrs(g, c.elem, 0, &len);
+        int cnt = 0, n_hop = 0;
+        for (int i = 0; i < *len; i++) {
+            const int32_t e = nb[i].elem;
+            if (visited[e]) continue;
+            visited[e] = 1;
+            if (n_visited) (*n_visited)++;
+            if (elem_allowed(g, e, allowed_rows)) cand[cnt++] = e;
+            else hop[n_hop++] = e;
+        }
+        for (int h = 0; h < n_hop && cnt < ORC_PA_CAP; h++) {
+            int32_t *len2;
+            hcand *nb2 = nbrs(g, hop[h], 0, &len2);
+            for (int j0 = 0; j0 < lm && cnt < ORC_PA_CAP; j0 += 64)
+                for (int j = j0; j < j0 + 64 && j < *len2; j++) {
+                    const int32_t e = nb2[j].elem;
+                    if (!elem_allowed(g, e, allowed_rows) || visited[e]) continue;
+                    visited[e] = 1;
+                    if (n_visited) (*n_visited)++;
+                    if (cnt < ORC_PA_CAP) cand[cnt++] = e;
+                }
+        }
+        for (int i = 0; i < cnt; i++) {
+            const int32_t e = cand[i];
+            const int always = wlen < ef;
+            f = W.a[0];
+            const double ed = index_distance(g->metric, g->dim, q, evec(g, e));
+            if (!(ed < f.dist || always)) continue;
+            scand sc = {ed, e};
+            sheap_push(&C, sc);
+            sheap_push(&W, sc);
+            wlen++;
+            if (wlen > ef) (void) sheap_pop(&W);
+        }
+    }
+    int nw = 0;
+    while (W.n > 0) w[nw++] = sheap_pop(&W);
+    free(C.a);
+    free(W.a);
+    free(hop);
+    return nw;
+}
+
 /* CheckElementCloser, :1024-1046 */
 static int check_closer(const orc_hnsw *g, const hcand *e, hcand *const *r, int nr)
 {
@@ -568,8 +648,25 @@ void orc_hnsw_export(const void *h, int32_t *level, int32_t *nbr0, int32_t *tid_
 /* GetScanItems, hnswscan.c:15-45 + the TID emission of hnswgettuple, :278-311: greedy descent with ef = 1, then
  * HnswSearchLayer(ef_search) on layer 0; candidates nearest first, every heap TID of an element (newest first, :286-296).
  * Returns the number of rows written (<= ef * 10); out_dist = the index distance as float8; visited count in *n_visited. */
+static int64_t hnsw_search_impl(const void *h, const float *q, int ef, int64_t *out_rows, double *out_dist, int32_t *out_elems,
+                                int64_t *n_visited, const uint8_t *allowed_rows);
+
 int64_t orc_hnsw_search(const void *h, const float *q, int ef, int64_t *out_rows, double *out_dist, int32_t *out_elems,
                         int64_t *n_visited)
+{
+    return hnsw_search_impl(h, q, ef, out_rows, out_dist, out_elems, n_visited, NULL);
+}
+
+/* the predicate-aware walk (search_layer_pa) behind the same descent and TID emission; the rows come back unfiltered: the
+ * caller applies allowed_rows to them like the executor's qual (an entry point that is not allowed can be among them) */
+int64_t orc_hnsw_search_pa(const void *h, const float *q, int ef, const uint8_t *allowed_rows, int64_t *out_rows,
+                           double *out_dist, int32_t *out_elems, int64_t *n_visited)
+{
+    return hnsw_search_impl(h, q, ef, out_rows, out_dist, out_elems, n_visited, allowed_rows);
+}
+
+static int64_t hnsw_search_impl(const void *h, const float *q, int ef, int64_t *out_rows, double *out_dist, int32_t *out_elems,
+                                int64_t *n_visited, const uint8_t *allowed_rows)
 {
     const orc_hnsw *g = (const orc_hnsw *) h;
     if (n_visited) *n_visited = 0;
@@ -585,7 +682,8 @@ int64_t orc_hnsw_search(const void *h, const float *q, int ef, int64_t *out_rows
         memcpy(ep, w, sizeof(scand) * (size_t) nw);
         n_ep = nw;
     }
-    int nw = search_layer(g, q, ep, n_ep, ef, 0, w, visited, n_visited);
+    int nw = allowed_rows ? search_layer_pa(g, q, ep, n_ep, ef, w, visited, n_visited, allowed_rows)
+                          : search_layer(g, q, ep, n_ep, ef, 0, w, visited, n_visited);
     int64_t out = 0;
     for (int i = nw - 1; i >= 0; i--) {                /* nearest first */
         const int32_t e = w[i].elem;

@@ -122,5 +122,7 @@ void    orc_hnsw_export(const void *h, int32_t *level, int32_t *nbr0, int32_t *t
                         int32_t *up_nbr, int32_t max_level);
 int64_t orc_hnsw_search(const void *h, const float *q, int ef, int64_t *out_rows, double *out_dist, int32_t *out_elems,
                         int64_t *n_visited);
+int64_t orc_hnsw_search_pa(const void *h, const float *q, int ef, const uint8_t *allowed_rows, int64_t *out_rows,
+                           double *out_dist, int32_t *out_elems, int64_t *n_visited);
 
 #endif

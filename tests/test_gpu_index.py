@@ -241,6 +241,58 @@ def test_hnsw_search_matches_the_oracle(ctx, oracle, hnsw20k, ef):
     corpus.free()
 
 
+@pytest.mark.parametrize("share", [0.05, 0.25])
+def test_hnsw_predicate_aware_walk(ctx, oracle, hnsw20k, share):
+    """vsr_hnsw_set_predicate_aware: the layer-0 walk applies the permission bitmap itself (ACORN-1 style two-hop expansion;
+    BASELINE config 5's "predicate-aware HNSW + RBAC").  ACORN's source is not part of the reference tree (PARITY UNPINNED
+    against it): the walk is pinned against the index oracle's restatement (same rows, distances and marked-element counts
+    on the same graph) and, by recall, against the exact filtered scan -- where it beats the plain graph + result filter at
+    the same ef_search by a wide margin when few rows are permitted.  Unfiltered queries are searched as before."""
+    import vsrbac
+    x, blk, doc, oh = hnsw20k
+    n = len(x)
+    rng = np.random.default_rng(int(share * 1000))
+    corpus = ctx.load_corpus(x, blk, doc)
+    ndocs = int(doc.max())
+    perms = [(1, int(d)) for d in rng.choice(np.arange(1, ndocs + 1), max(1, int(ndocs * share)), replace=False)]
+    ur = [(1, 1)]
+    corpus.load_rbac(ur, perms)
+    mask = oracle.user_row_mask(1, ur, perms, doc)
+    gpu = corpus.load_hnsw(oh.export())
+    nq, k = 16, 20
+    q = x[rng.integers(0, n, nq)] + rng.integers(-2, 3, (nq, x.shape[1])).astype(np.float32)
+    for ef in (20, 100):
+        recalls = {}
+        for aware in (False, True):
+            gpu.set_predicate_aware(aware)
+            for flt in (corpus.filter_for_user(1, vsrbac.BITMAP), corpus.filter_for_user(1, vsrbac.RANGES)):
+                res, vis = gpu.search(q, k, ef, "l2", [flt] * nq)
+                hits = 0
+                for i in range(nq):
+                    rows_o, dist_o, _, nv = oh.search_predicate_aware(q[i], ef, mask) if aware else oh.search(q[i], ef)
+                    keep = mask[rows_o] != 0
+                    want, wd = rows_o[keep][:k], dist_o[keep][:k]
+                    assert res.counts[i] == want.size, (aware, ef, i, res.counts[i], want.size)
+                    np.testing.assert_array_equal(res.rows[i, :want.size], want)
+                    np.testing.assert_array_equal(res.dist[i, :want.size], np.sqrt(wd).astype(np.float32))
+                    assert vis[i] == nv, (aware, ef, i, vis[i], nv)
+                    exact, _ = oracle.filtered_topk("l2", x, q[i], k, doc, blk, mask)
+                    hits += len(set(res.rows[i, :want.size].tolist()) & set(exact.tolist()))
+                recalls[aware] = hits / (nq * k)
+            res0, vis0 = gpu.search(q, k, ef, "l2")                       # no filter: the same walk either way
+            for i in range(nq):
+                rows_o, _, _, nv = oh.search(q[i], ef)
+                np.testing.assert_array_equal(res0.rows[i, :min(k, rows_o.size)], rows_o[:k])
+                assert vis0[i] == nv
+        print(f"hnsw share={share} ef={ef}: recall@{k} plain+filter {recalls[False]:.3f}, predicate-aware {recalls[True]:.3f}")
+        assert recalls[True] >= recalls[False]
+        if ef == 100:
+            assert recalls[True] >= 0.6, recalls
+    gpu.set_predicate_aware(False)
+    gpu.free()
+    corpus.free()
+
+
 def test_index_caches_forget_freed_filters(ctx, oracle, hnsw20k):
     """The index-side caches (IVFFlat view-order bitmaps and probe parts, HNSW row bitmaps) are keyed by the filter's
     never-reused id and purged when the filter dies: a filter created after another one was freed -- typically at the

@@ -85,3 +85,31 @@ def test_ivfflat_self_query_recall(oracle):
     unit = x / np.linalg.norm(x, axis=1, keepdims=True)
     ivf2 = IvfIndex(oracle, "cosine", unit, lists=20, seed=4)
     np.testing.assert_allclose(np.linalg.norm(ivf2.centers, axis=1), 1.0, atol=1e-5)
+
+
+def test_predicate_aware_walk_of_the_oracle(oracle):
+    """search_layer_pa (the restatement of K4's predicate-aware walk): with every row allowed it is HnswSearchLayer itself;
+    with few rows allowed everything it returns besides the entry point is allowed, and its recall against the exact
+    filtered scan beats filtering the plain walk's results at the same ef_search."""
+    rng = np.random.default_rng(5)
+    n, dim, k, ef = 6000, 16, 10, 40
+    x = np.clip(np.rint(np.abs(rng.normal(0, 45, (n, dim)))), 0, 255).astype(np.float32)
+    h = HnswIndex(oracle, "l2", x, m=8, ef_construction=32, seed=2)
+    allowed = (rng.random(n) < 0.1).astype(np.uint8)
+    doc = np.arange(n, dtype=np.int32) + 1
+    blk = np.arange(n, dtype=np.int64) + 1
+    hits_pa = hits_plain = 0
+    for i in range(20):
+        q = x[rng.integers(0, n)] + rng.integers(-2, 3, dim).astype(np.float32)
+        r_all, d_all, _, nv_all = h.search_predicate_aware(q, ef, np.ones(n, dtype=np.uint8))
+        r_pl, d_pl, _, nv_pl = h.search(q, ef)
+        np.testing.assert_array_equal(r_all, r_pl)
+        np.testing.assert_array_equal(d_all, d_pl)
+        assert nv_all == nv_pl
+        r_pa, d_pa, _, _ = h.search_predicate_aware(q, ef, allowed)
+        assert (allowed[r_pa] != 0).sum() >= r_pa.size - 1            # (the entry point of layer 0 may be a row that is not allowed)
+        assert (np.diff(d_pa) >= 0).all()
+        exact, _ = oracle.filtered_topk("l2", x, q, k, doc, blk, allowed)
+        hits_pa += len(set(r_pa[allowed[r_pa] != 0][:k].tolist()) & set(exact.tolist()))
+        hits_plain += len(set(r_pl[allowed[r_pl] != 0][:k].tolist()) & set(exact.tolist()))
+    assert hits_pa > hits_plain and hits_pa >= 0.8 * 20 * k, (hits_pa, hits_plain)

@@ -20,6 +20,14 @@
 //                   status 1 and is re-run by the host entry point with the global bitmap
 //   VIS_GLOBAL      one bitmap per query in global memory (round 2's only form; n_elem / 8 bytes per query, cleared per call)
 // Upper layers (ef = 1) keep a short visited list in LDS.
+//
+// predicate_aware (vsr_hnsw_set_predicate_aware; off by default = pgvector's behaviour, where the executor filters what the
+// index returns): the layer-0 walk itself applies the query's permission bitmap, in the manner of ACORN-1 (Patel et al., the
+// library acorn_benchmark/src/acorn_search.cpp:144-181 calls; its source is not in the reference tree, so this variant is
+// pinned by the tests' CPU restatement of THIS walk and by recall against the exact filtered scan, not by ACORN's code):
+// W and C hold permitted elements only; expanding c takes c's unvisited neighbours that are permitted, and for every
+// unvisited neighbour that is NOT permitted its permitted unvisited neighbours (two hops), in list order, up to HN_NBR
+// candidates per expansion.  The descent through the upper layers and the entry point are unfiltered.
 #pragma once
 #include "vsr_device.h"
 #include "vsr_topk.h"
@@ -45,6 +53,7 @@ struct HnswParams {
     const int32_t*  tid_count = nullptr;     // element -> heap TIDs (<= 10)
     const int32_t*  tids = nullptr;          // [n_elem][10] internal rows
     const uint64_t* const* bitmaps = nullptr;  // per query: permission bitmap over internal rows, or nullptr
+    int             predicate_aware = 0;     // 1: the layer-0 walk applies the bitmap (see above); 0: only the results are filtered
     uint32_t        ef = 0, k = 0, caps = 0;   // caps: capacity of S (>= ef + 2m)
     int             vis_mode = VIS_GLOBAL;
     uint32_t        vis_words = 0;           // LDS bitmap / global bitmap: 32-bit words per query; LDS hash: slots (power of two)
@@ -156,6 +165,17 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const HnswParams p)
         wave_sync();
     };
 
+    const uint64_t* bm = p.bitmaps ? p.bitmaps[qi] : nullptr;
+    const bool pa = p.predicate_aware && bm != nullptr;
+    // element e is permitted when one of its heap rows is
+    auto permitted = [&](uint32_t e) -> bool {
+        const uint32_t nt = (uint32_t) p.tid_count[e];
+        for (uint32_t t = 0; t < nt; ++t) {
+            const uint32_t row = (uint32_t) p.tids[(size_t) e * 10 + t];
+            if ((bm[row >> 6] >> (row & 63)) & 1ull) return true;
+        }
+        return false;
+    };
     uint32_t count = 0;                      // entries of S
     uint32_t pushed = 0;                     // wlen of the reference: pushes so far (never decremented)
     uint32_t first_open = 0;                 // every entry before this position is expanded
@@ -251,6 +271,43 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const HnswParams p)
                 const int32_t slot = p.up_slot[ce];
                 nl = slot >= 0 ? p.up_nbr + ((size_t) slot * p.max_level + (uint32_t) (lc - 1)) * p.m : nullptr;
             }
+            if (pa && lc == 0) {
+                // ---- predicate-aware expansion: permitted neighbours, then the permitted neighbours of the others ----
+                int32_t* hop = reinterpret_cast<int32_t*>(nd);               // (nd is free until distances(): <= 2m <= 200 ids)
+                int n_hop = 0;
+                uint32_t marked = 0;
+                for (uint32_t j0 = 0; j0 < lm; j0 += 64) {
+                    const uint32_t j = j0 + (uint32_t) lane;
+                    const int32_t my = j < lm ? nl[j] : -1;
+                    const bool fresh = my >= 0 && visit((uint32_t) my);
+                    const bool okp = fresh && permitted((uint32_t) my);
+                    const uint64_t fm = __ballot(okp), hm = __ballot(fresh && !okp);
+                    if (okp) nb[cnt + __popcll(fm & ((1ull << lane) - 1ull))] = my;
+                    if (fresh && !okp) hop[n_hop + __popcll(hm & ((1ull << lane) - 1ull))] = my;
+                    cnt += __popcll(fm);
+                    n_hop += __popcll(hm);
+                    marked += (uint32_t) __popcll(fm | hm);
+                    wave_sync();
+                }
+                for (int h = 0; h < n_hop && cnt < HN_NBR; ++h) {
+                    const int32_t* nl2 = p.nbr0 + (size_t) (uint32_t) hop[h] * 2 * p.m;
+                    for (uint32_t j0 = 0; j0 < lm && cnt < HN_NBR; j0 += 64) {
+                        const uint32_t j = j0 + (uint32_t) lane;
+                        const int32_t my = j < lm ? nl2[j] : -1;
+                        const bool ok2 = my >= 0 && permitted((uint32_t) my) && visit((uint32_t) my);
+                        const uint64_t fm = __ballot(ok2);
+                        const int at = cnt + __popcll(fm & ((1ull << lane) - 1ull));
+                        if (ok2 && at < HN_NBR) nb[at] = my;                 // (beyond the cap: marked visited, dropped)
+                        marked += (uint32_t) __popcll(fm);
+                        cnt += __popcll(fm);
+                        if (cnt > HN_NBR) cnt = HN_NBR;
+                        wave_sync();
+                    }
+                }
+                visited_l0 += marked;
+                hash_used += marked;
+                if (p.vis_mode == VIS_LDS_HASH && hash_used * 4u > p.vis_words * 3u) { overflow = true; break; }
+            } else {
             for (uint32_t j0 = 0; j0 < lm && nl; j0 += 64) {
                 const uint32_t j = j0 + (uint32_t) lane;
                 const int32_t my = j < lm ? nl[j] : -1;
@@ -281,6 +338,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const HnswParams p)
                 visited_l0 += cnt;
                 hash_used += (uint32_t) cnt;
                 if (p.vis_mode == VIS_LDS_HASH && hash_used * 4u > p.vis_words * 3u) { overflow = true; break; }
+            }
             }
             if (cnt == 0) continue;
             distances(cnt);
@@ -337,7 +395,6 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const HnswParams p)
     }
 
     // hnswgettuple: elements nearest first, their heap TIDs newest first, the permission bit, the first k
-    const uint64_t* bm = p.bitmaps ? p.bitmaps[qi] : nullptr;
     uint32_t out = 0;
     for (uint32_t base = 0; base < count && out < p.k; base += 64) {
         const uint32_t i = base + (uint32_t) lane;

@@ -3041,6 +3041,7 @@ struct vsr_hnsw {
     DevBuf d_q, d_vis, d_out, d_bm;
     PinBuf h_out, h_bm;
     int last_mode = -1;                              // visited form of the last launch (HnswVisited)
+    int predicate_aware = 0;                         // vsr_hnsw_set_predicate_aware
 };
 
 extern "C" int vsr_hnsw_free(vsr_hnsw* h)
@@ -3277,6 +3278,13 @@ extern "C" int vsr_hnsw_build(vsr_corpus* c, int m, int ef_construction, int met
 }
 
 // what a build left: elements, entry point, its level, the highest level (for reports and tests)
+extern "C" int vsr_hnsw_set_predicate_aware(vsr_hnsw* h, int on)
+{
+    if (!h) return fail(VSR_ERR_INVALID, "vsr_hnsw_set_predicate_aware: index is NULL");
+    h->predicate_aware = on ? 1 : 0;
+    return VSR_OK;
+}
+
 extern "C" int vsr_hnsw_info(const vsr_hnsw* h, int32_t* n_elem, int32_t* entry, int32_t* entry_level, int32_t* max_level)
 {
     if (!h) return fail(VSR_ERR_INVALID, "vsr_hnsw_info: index is NULL");
@@ -3367,6 +3375,7 @@ static int hnsw_launch(vsr_hnsw* h, vsr_ctx* ctx, const float* d_q, uint32_t q_s
     p.tid_count = h->d_tid_count;
     p.tids = h->d_tids;
     p.bitmaps = d_bm;
+    p.predicate_aware = h->predicate_aware;
     p.ef = (uint32_t) ef;
     p.k = (uint32_t) k;
     p.caps = (uint32_t) (2 * ef + 2 * h->m + 64);

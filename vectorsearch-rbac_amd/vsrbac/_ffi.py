@@ -70,6 +70,7 @@ SYMBOLS = {
     "vsr_hnsw_search_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vsr_hnsw_build": (_i, [_vp, _i, _i, _i, C.c_uint64, _vp]),
     "vsr_hnsw_info": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "vsr_hnsw_set_predicate_aware": (_i, [_vp, _i]),
     "vsr_vector_norms": (_i, [_vp, _vp, _i64, _i, _vp]),
     "vsr_l2_normalize": (_i, [_vp, _vp, _i64, _i, _vp]),
     "vsr_spherical_distances": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),

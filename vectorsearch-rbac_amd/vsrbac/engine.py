@@ -453,6 +453,11 @@ class HnswIndex:
         except Exception:
             pass
 
+    def set_predicate_aware(self, on=True):
+        """The layer-0 walk applies the query's filter itself (ACORN-1 style two-hop expansion) instead of leaving the
+        filtering of the results to the caller's side (vsr_hnsw_set_predicate_aware)."""
+        check(self._lib.vsr_hnsw_set_predicate_aware(self._h, 1 if on else 0))
+
     def info(self):
         """(elements, entry point, its level, highest level) of the graph."""
         v = [C.c_int32() for _ in range(4)]
