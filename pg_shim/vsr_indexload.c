@@ -395,6 +395,8 @@ VsrRunIndexSearch(IndexScanDesc scan, VsrPgScanOpaque so, bool is_hnsw, int ef_o
 		if (pc->graph == NULL)
 			pc->graph = VsrLoadHnswGraph(scan->indexRelation, pc);
 		if (pc->graph != NULL)
+			VsrCheck(vsr_hnsw_set_predicate_aware(pc->graph, vsr_pg_predicate_aware ? 1 : 0));
+		if (pc->graph != NULL)
 			VsrCheck(vsr_hnsw_search(pc->graph, q->x, 1, q->dim, k, ef_or_probes, VsrMetricOf(scan->indexRelation),
 									 filter ? &filter : NULL, blk, NULL, rowidx, dist, &count, NULL));
 	}

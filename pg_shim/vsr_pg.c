@@ -31,6 +31,7 @@
 int			vsr_pg_device = 0;
 int			vsr_pg_mode = VSR_PG_MODE_POSTFILTER;
 bool		vsr_pg_index_faithful = false;
+bool		vsr_pg_predicate_aware = false;
 char	   *vsr_pg_sidecar = NULL;
 static int	vsr_pg_epoch = 0;	/* GUC vsrbac.epoch: any change drops every cached corpus (an explicit refresh) */
 static vsr_sc_conn *sidecar_conn = NULL;
@@ -540,6 +541,10 @@ VsrPgInit(void)
 							 "Answer index scans with the index's own graph walk / list probe on the GPU (same candidates and "
 							 "recall as stock pgvector) instead of the exact filtered search", NULL, &vsr_pg_index_faithful,
 							 false, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomBoolVariable("vsrbac.predicate_aware",
+							 "With vsrbac.index_faithful: the HNSW walk applies the current user's permissions while it walks "
+							 "(ACORN-style two-hop expansion) instead of filtering what the index returns", NULL,
+							 &vsr_pg_predicate_aware, false, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomStringVariable("vsrbac.sidecar",
 							   "UNIX socket of the resident GPU process (pg_shim/vsr_sidecar); empty: every backend loads its own copy",
 							   "With a sidecar the corpus survives the backend: a new connection per search, as the reference harness "

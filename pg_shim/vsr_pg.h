@@ -40,6 +40,7 @@ typedef enum
 extern int	vsr_pg_device;		/* GUC vsrbac.device */
 extern int	vsr_pg_mode;		/* GUC vsrbac.mode */
 extern bool vsr_pg_index_faithful;	/* GUC vsrbac.index_faithful: reproduce the index's own answer (vsr_indexload.c) */
+extern bool vsr_pg_predicate_aware;	/* GUC vsrbac.predicate_aware: the in-backend HNSW walk filters while it walks (not through the sidecar) */
 extern char *vsr_pg_sidecar;	/* GUC vsrbac.sidecar: socket of the resident GPU process ("" = in-process, per backend) */
 
 /*
