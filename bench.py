@@ -276,6 +276,46 @@ def hnsw_legs(args, torch, ctx, orc, box, qvec, k, dev):
                        "resident, one launch per call).  roofline: the row bytes of every distance evaluation (visited "
                        "elements x d x 4; SURVEY 8d's gather figure) over the launch time -- a graph walk is a chain of "
                        "dependent gathers, latency- not bandwidth-bound, so the fraction is small by nature"}
+        # BASELINE config 5's mode on the same graph: a predicate that admits ~10 % of the rows (every 10th document of 100
+        # rows), the walk that applies it while it walks (vsr_hnsw_set_predicate_aware) beside the plain walk whose results are
+        # filtered, both against the exact filtered scan of the oracle
+        try:
+            import vsrbac as _v
+            pmask = (((np.arange(len(sub)) // 100) % 10) == 3).astype(np.uint8)
+            pf = c2.filter_from_bytemask(pmask, _v.BITMAP)
+            pfl = c2.pack_filters([pf] * nq)
+            pexact = [set(orc.filtered_topk("l2", sub, hq[i], k, None, None, pmask)[0].tolist()) for i in range(len(hq))]
+            prec = lambda got: float(np.mean([len(set(np.asarray(g).tolist()) & e) / max(1, len(e)) for g, e in zip(got, pexact)]))
+            psweep = []
+            for ef in (100, 400):
+                pt = {"ef_search": ef}
+                for aware in (False, True):
+                    gidx.set_predicate_aware(aware)
+                    call = lambda: gidx.search_device(ptr(d_q), nq, k, ef, "l2", pfl, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist),
+                                                      ptr(o_cnt), ptr(o_vis))
+                    call()
+                    ctx.synchronize()
+                    th = time.perf_counter()
+                    for _ in range(3):
+                        call()
+                    ctx.synchronize()
+                    gs = (time.perf_counter() - th) / 3
+                    rows_g, cnt_g = o_row.cpu().numpy(), o_cnt.cpu().numpy()
+                    if (cnt_g < 0).any():
+                        res, _ = gidx.search(gq, k, ef, "l2", [pf] * nq)
+                        rows_g, cnt_g = res.rows, res.counts
+                    pt["predicate_aware" if aware else "plain_walk_then_filter"] = {
+                        "qps": round(nq / gs, 1), "recall_at_k": round(prec([rows_g[i][:int(cnt_g[i])] for i in range(len(hq))]), 4),
+                        "rows_returned_per_query": round(float(np.maximum(cnt_g, 0).mean()), 1)}
+                psweep.append(pt)
+            gidx.set_predicate_aware(False)
+            gpu["predicate_aware"] = {"permitted_fraction": round(float(pmask.mean()), 3), "sweep": psweep,
+                                      "note": "K4 with the permission bitmap applied inside the layer-0 walk (ACORN-1 style two-hop "
+                                              "expansion; parity pinned by the index oracle's restatement, ACORN's own source is not in "
+                                              "the reference tree) against the exact filtered scan; the plain walk returns what is left "
+                                              "of its ef_search candidates after the filter (pgvector's behaviour)"}
+        except Exception as exc:
+            gpu["predicate_aware"] = {"error": repr(exc)}
         gidx.free()
         # CREATE INDEX on the GPU (vsr_hnsw_build: batched insertion) over the same rows: build time beside the CPU port's, and
         # the same ef_search sweep on the graph it leaves (another graph than the serial build's: recall is the parity measure)
