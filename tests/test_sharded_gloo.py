@@ -34,6 +34,27 @@ class OracleShardEngine:
         return {"keys": torch.from_numpy(keys.view(np.int64)), "block": torch.from_numpy(blk),
                 "doc": torch.from_numpy(doc), "dist": torch.from_numpy(dist)}
 
+    def search_local_index(self, kind, queries, k, metric, filters, probes=None, ef_search=None):
+        """An "index" over this shard that looks at every `probes`-th row only (a stand-in for an approximate index: each
+        rank's list is the exact answer over the rows its index reaches); keys as GpuShardEngine builds them for index
+        results: the RETURNED distance and the global row."""
+        from vsrbac.sharded import monotone_keys
+        torch = self.torch
+        nq = len(queries)
+        keys = np.full((nq, k), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+        blk = np.full((nq, k), -1, dtype=np.int64)
+        doc = np.full((nq, k), -1, dtype=np.int32)
+        dist = np.full((nq, k), np.inf, dtype=np.float32)
+        reach = np.zeros(len(self.x), dtype=np.uint8)
+        reach[::max(1, int(probes or 1))] = 1
+        for i, q in enumerate(queries):
+            idx, d = self.orc.filtered_topk(metric, self.x, q, k, self.doc, self.blk, self.masks[i] & reach)
+            m = idx.size
+            keys[i, :m] = monotone_keys(d.astype(np.float32), idx + self.lo)
+            blk[i, :m], doc[i, :m], dist[i, :m] = self.blk[idx], self.doc[idx], d.astype(np.float32)
+        return {"keys": torch.from_numpy(keys.view(np.int64)), "block": torch.from_numpy(blk),
+                "doc": torch.from_numpy(doc), "dist": torch.from_numpy(dist)}
+
     def finalize(self, local):
         return local["block"], local["doc"], local["dist"], None
 
@@ -63,9 +84,11 @@ def _worker(rank, world, port, n, k, q_out):
     queries = x[[3, 77, 500, 1234]]
     lo, hi = shard_bounds(n, world, rank, align=10)
     eng = OracleShardEngine(x[lo:hi], doc[lo:hi], blk[lo:hi], lo, [m[lo:hi] for m in masks])
-    out = ShardedSearcher(eng, world, rank, dist).search(queries, k, "l2", None)
+    searcher = ShardedSearcher(eng, world, rank, dist)
+    out = searcher.search(queries, k, "l2", None)
+    out_ix = searcher.search(queries, k, "l2", None, index="ivf", probes=3)       # per-rank index scans, same collectives
     if rank == 0:
-        q_out.put([np.asarray(o) for o in out])
+        q_out.put([np.asarray(o) for o in out] + [np.asarray(o) for o in out_ix])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,7 +107,7 @@ def test_two_rank_gloo_matches_unsharded_oracle(oracle):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, k, q)) for r in range(world)]
     for p in procs:
         p.start()
-    blk, doc, dist, cnt = q.get(timeout=150)
+    blk, doc, dist, cnt, iblk, idoc, idist, icnt = q.get(timeout=150)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -99,3 +122,15 @@ def test_two_rank_gloo_matches_unsharded_oracle(oracle):
         np.testing.assert_array_equal(blk[i, :idx.size], blks[idx])
         np.testing.assert_array_equal(doc[i, :idx.size], docs[idx])
         np.testing.assert_array_equal(dist[i, :idx.size], d.astype(np.float32))
+    # the index path: every rank's stand-in index reaches every 3rd row OF ITS SHARD; the merged list is the exact answer over
+    # the union of what the ranks' indexes reach (the reference's per-partition indexes + client-side merge)
+    reach = np.zeros(n, dtype=np.uint8)
+    from vsrbac.sharded import shard_bounds
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r, align=10)
+        reach[lo:hi:3] = 1
+    for i, qi in enumerate([3, 77, 500, 1234]):
+        idx, d = oracle.filtered_topk("l2", x, x[qi], k, docs, blks, masks[i] & reach)
+        assert icnt[i] == idx.size
+        np.testing.assert_array_equal(iblk[i, :idx.size], blks[idx])
+        np.testing.assert_array_equal(idist[i, :idx.size], d.astype(np.float32))
