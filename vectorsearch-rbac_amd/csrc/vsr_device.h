@@ -347,7 +347,7 @@ hipError_t launch_gather_rows(const float4* src, const float* src_norm, const ui
                               float4* dst, float* dst_norm, hipStream_t s);
 hipError_t launch_view_bitmap(const uint32_t* rank, uint32_t n_rows, const uint2* tiles, uint32_t n_tiles, const uint64_t* bitmap,
                               uint64_t* out, hipStream_t s);
-hipError_t launch_ivf_probe(const float* queries, uint32_t q_stride, uint32_t nq, const float* centers, int dim, int lists, int probes,
+hipError_t launch_ivf_probe(const float* queries, uint32_t q_stride, uint32_t nq, const float* centers_t /* [dim][lists] */, int dim, int lists, int probes,
                             int metric, int32_t* out, hipStream_t s);
 hipError_t launch_vector_fn(int mode, const float* a, const float* b, int64_t n, int dim, int b_broadcast, double* out_d,
                             float* out_f, int* overflow, hipStream_t s);

@@ -1204,7 +1204,7 @@ hipError_t launch_view_bitmap(const uint32_t* rank, uint32_t n_rows, const uint2
 // GetScanLists (ivfscan.c:36-107): per query the `probes` nearest of `lists` centres under the opclass distance (L2
 // squared, or negative inner product), nearest first, the lower list id first among equals.  One workgroup per query.
 // The sums run in the order and rounding of vector.c's loops compiled without contraction (one lane per centre).
-__global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, uint32_t q_stride, const float* centers, int dim,
+__global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, uint32_t q_stride, const float* centers_t, int dim,
                                                         int lists, int probes, int metric, int32_t* out)
 {
     // one 32-bit monotone image of the distance per list (the list id is the slot): 32768 lists, the reloption's maximum
@@ -1214,16 +1214,19 @@ __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, ui
     __shared__ uint64_t s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* q = queries + (size_t) blockIdx.x * q_stride;         // (corpus rows as queries: the index build's assignment)
+    // centers_t[j][c]: the centres TRANSPOSED (element j of all lists contiguous), so that the 64 lanes of a wave -- one centre
+    // each -- read 256 contiguous bytes per element instead of 64 lines 4 * dim bytes apart; every lane still adds its own
+    // centre's terms in element order (the reference's loop), and q[j] is one broadcast load
     for (int c = tid; c < lists; c += 256) {
-        const float* x = centers + (size_t) c * dim;
+        const float* x = centers_t + c;
         float sum = 0.0f;
         if (metric == M_L2) {
             for (int j = 0; j < dim; ++j) {
-                const float d = __fsub_rn(x[j], q[j]);
+                const float d = __fsub_rn(x[(size_t) j * lists], q[j]);
                 sum = __fadd_rn(sum, __fmul_rn(d, d));
             }
         } else {
-            for (int j = 0; j < dim; ++j) sum = __fadd_rn(sum, __fmul_rn(x[j], q[j]));
+            for (int j = 0; j < dim; ++j) sum = __fadd_rn(sum, __fmul_rn(x[(size_t) j * lists], q[j]));
             sum = -sum;
         }
         keys[c] = mono_bits(sum);
@@ -1253,7 +1256,7 @@ __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* queries, ui
     }
 }
 
-hipError_t launch_ivf_probe(const float* queries, uint32_t q_stride, uint32_t nq, const float* centers, int dim, int lists, int probes,
+hipError_t launch_ivf_probe(const float* queries, uint32_t q_stride, uint32_t nq, const float* centers_t, int dim, int lists, int probes,
                             int metric, int32_t* out, hipStream_t s)
 {
     if (nq == 0) return hipSuccess;
@@ -1264,7 +1267,7 @@ hipError_t launch_ivf_probe(const float* queries, uint32_t q_stride, uint32_t nq
                                            (int) lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ivf_probe_kernel, dim3(nq), dim3(256), lds, s, queries, q_stride, centers, dim, lists, probes, metric, out);
+    hipLaunchKernelGGL(ivf_probe_kernel, dim3(nq), dim3(256), lds, s, queries, q_stride, centers_t, dim, lists, probes, metric, out);
     return hipGetLastError();
 }
 

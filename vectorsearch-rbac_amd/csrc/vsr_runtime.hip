@@ -2516,20 +2516,26 @@ static int host_search(vsr_corpus* c, const float* queries, int nq, int dim, int
     const size_t o_blk = 0, o_row = align_up(o_blk + nk * 8, 256), o_doc = align_up(o_row + nk * 8, 256),
                  o_dist = align_up(o_doc + nk * 4, 256), o_cnt = align_up(o_dist + nk * 4, 256),
                  total = align_up(o_cnt + (size_t) nq * 4, 256);
-    if ((rc = ctx->d_out.reserve(total))) return rc;
-    if ((rc = ctx->h_out.reserve(total))) return rc;
-    char* d = ctx->d_out.as<char>();
+    // [results | flags] in pinned memory.  Small results (the harness's one query per call) are written there by the kernels
+    // themselves -- the block is mapped into the device's address space -- so a call is its launches, a 4-byte-per-query copy of
+    // the flags and ONE wait; larger ones go through device memory and one packed copy.
+    const size_t o_flags = total, total_h = align_up(o_flags + (size_t) nq * 4, 256);
+    const bool direct = total <= 64 * 1024;
+    if (!direct && (rc = ctx->d_out.reserve(total))) return rc;
+    if ((rc = ctx->h_out.reserve(total_h))) return rc;
+    char* d = direct ? static_cast<char*>(ctx->h_out.dp) : ctx->d_out.as<char>();
+    char* h = ctx->h_out.as<char>();
     auto run = [&](const float* qs, int n, const vsr_filter* const* fs, int level) -> int {
         int r = search_impl(ctx, c, qs, nullptr, n, dim, k, metric, fs, reinterpret_cast<int64_t*>(d + o_blk),
                             reinterpret_cast<int32_t*>(d + o_doc), reinterpret_cast<int64_t*>(d + o_row),
                             reinterpret_cast<float*>(d + o_dist), reinterpret_cast<int32_t*>(d + o_cnt), nullptr, level);
         if (r) return r;
-        HIPCHK(hipMemcpyAsync(ctx->h_out.p, d, total, hipMemcpyDeviceToHost, ctx->stream));
+        if (!direct) HIPCHK(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h + o_flags, ctx->d_flags.p, (size_t) n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         return VSR_OK;
     };
     if ((rc = run(queries, nq, filters, 2))) return rc;
-    char* h = ctx->h_out.as<char>();
     memcpy(out_blk, h + o_blk, nk * 8);
     if (out_row) memcpy(out_row, h + o_row, nk * 8);
     if (out_doc) memcpy(out_doc, h + o_doc, nk * 4);
@@ -2537,8 +2543,7 @@ static int host_search(vsr_corpus* c, const float* queries, int nq, int dim, int
     memcpy(out_cnt, h + o_cnt, (size_t) nq * 4);
 
     // screening flags: re-run the (rare) flagged queries one tier down -- coarse planes -> fine planes -> exact kernels
-    std::vector<int32_t> flags((size_t) nq, 0);
-    HIPCHK(hipMemcpy(flags.data(), ctx->d_flags.p, (size_t) nq * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> flags(reinterpret_cast<const int32_t*>(h + o_flags), reinterpret_cast<const int32_t*>(h + o_flags) + nq);
     std::vector<int> redo;
     for (int i = 0; i < nq; ++i)
         if (flags[(size_t) i]) redo.push_back(i);
@@ -2551,7 +2556,7 @@ static int host_search(vsr_corpus* c, const float* queries, int nq, int dim, int
             if (filters) f2[j] = filters[redo[j]];
         }
         if ((rc = run(q2.data(), (int) redo.size(), f2.data(), level))) return rc;
-        HIPCHK(hipMemcpy(flags.data(), ctx->d_flags.p, redo.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        memcpy(flags.data(), h + o_flags, redo.size() * sizeof(int32_t));
         std::vector<int> still;
         for (size_t j = 0; j < redo.size(); ++j) {
             if (flags[j] && level > 0) {                      // unproven again: one more tier down
@@ -2740,6 +2745,15 @@ extern "C" int vsr_spherical_distances(vsr_ctx* ctx, const float* a, const float
 // ---------------------------------------------------------------------------------------------
 // K3: IVFFlat list probe (ivfscan.c:36-176, 339-389) over a list-ordered view of the corpus
 // ---------------------------------------------------------------------------------------------
+// [lists][dim] -> [dim][lists]: the layout ivf_probe_kernel reads (vsr_kernels.hip)
+static std::vector<float> transpose_centers(const float* centers, int lists, int dim)
+{
+    std::vector<float> t((size_t) lists * dim);
+    for (int c = 0; c < lists; ++c)
+        for (int j = 0; j < dim; ++j) t[(size_t) j * lists + c] = centers[(size_t) c * dim + j];
+    return t;
+}
+
 struct vsr_ivf {
     vsr_corpus* main = nullptr;
     vsr_corpus* view = nullptr;                      // list-ordered rows; view->base = main
@@ -2827,7 +2841,10 @@ extern "C" int vsr_ivf_load(vsr_corpus* c, const float* centers, int lists, cons
         if (!all.empty()) HIPCHK(hipMemcpy(v->d_all_tiles, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
     }
     HIPCHK(hipMalloc(&ivf->d_centers, (size_t) lists * c->dim * sizeof(float)));
-    HIPCHK(hipMemcpy(ivf->d_centers, centers, (size_t) lists * c->dim * sizeof(float), hipMemcpyHostToDevice));
+    {                                                       // transposed for the probe kernel: element j of every list contiguous
+        std::vector<float> ct = transpose_centers(centers, lists, c->dim);
+        HIPCHK(hipMemcpy(ivf->d_centers, ct.data(), ct.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ivf->view = v.release();
     ivf->list_filters.assign((size_t) lists, nullptr);
@@ -3017,7 +3034,8 @@ extern "C" int vsr_ivf_assign(vsr_corpus* c, const float* centers, int lists, in
     int rc;
     if ((rc = d_centers.reserve((size_t) lists * c->dim * sizeof(float)))) return rc;
     if ((rc = d_out.reserve((size_t) n * sizeof(int32_t)))) return rc;
-    HIPCHK(hipMemcpyAsync(d_centers.p, centers, (size_t) lists * c->dim * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    const std::vector<float> ct = transpose_centers(centers, lists, c->dim);      // (outlives the copy: synchronised below)
+    HIPCHK(hipMemcpyAsync(d_centers.p, ct.data(), ct.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     // cosine opclass: rows and centres are compared by the negative inner product (spherical k-means, vector.sql:323-327)
     HIPCHK(launch_ivf_probe(reinterpret_cast<const float*>(c->d_rows), (uint32_t) c->stride4 * 4, (uint32_t) n,
                             d_centers.as<float>(), c->dim, lists, 1, metric == VSR_METRIC_L2 ? M_L2 : M_IP, d_out.as<int32_t>(),
