@@ -930,7 +930,7 @@ def main():
             # batch once.  The driver's W = 5 steps are 2 ms of GPU work behind seconds of host-side setup with the GPU idle;
             # measured, a 20-step region then runs at 0.38-0.40 ms per step against 0.34 after this pass (sessions' workspaces at
             # their final size, GPU out of its idle power state) -- the rate of the `sustained` leg and of any serving process.
-            if os.environ.get("VSR_BENCH_NO_SETUP_PASS") != "1":
+            if os.environ.get("VSR_BENCH_NO_SETUP_PASS") != "1" and not state.get("skip_setup_pass"):
                 for _ in range(nb * max(1, state["n_sess"])):
                     step()
                 finish_groups()
@@ -1021,6 +1021,20 @@ def main():
                 "flagged_in_batch": int(np.count_nonzero(fl))}
 
     # ---- the timed legs ----
+    # first the headline leg WITHOUT the setup pass, exactly as the driver's flags alone would run it (W warm-up steps behind an
+    # idle GPU): reported beside the headline as `cold_start`, so that the line shows what the setup pass changes
+    cold = None
+    if world == 1 and os.environ.get("VSR_BENCH_NO_SETUP_PASS") != "1":
+        state["skip_setup_pass"] = True
+        try:
+            rc0 = timed_leg(legs[0], args.steps, args.warmup)
+            if not rc0["flagged"]:
+                cold = {"value": round(nq * args.steps / rc0["dt"], 1), "unit": "queries/s",
+                        "ms_per_step": round(rc0["dt"] / args.steps * 1e3, 4),
+                        "note": "the headline leg run first and WITHOUT the untimed setup pass (config.setup_pass): W warm-up steps "
+                                "behind seconds of host-side setup, then the K timed steps"}
+        finally:
+            state["skip_setup_pass"] = False
     results = {}
     for leg in legs:
         r = timed_leg(leg, args.steps, args.warmup)
@@ -1132,6 +1146,8 @@ def main():
         "host_library_ms_per_step": main_rec["host_library_ms_per_step"],
         "screening_flagged_queries": main_rec["screening_flagged_queries"],
     }
+    if cold:
+        out["cold_start"] = cold
     for leg in legs[1:]:
         out[leg] = recs[leg]
         out[leg]["workload"] = (f"same corpus, users and queries; filter = per-user row-level-security bitmap tested in "
