@@ -70,11 +70,14 @@ struct DevBuf {
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return VSR_OK;
+        const bool regrow = p != nullptr;
         if (p) (void) hipFree(p);
         p = nullptr;
         cap = 0;
+        // a quarter of slack the first time; a buffer that had to grow once doubles: hipFree / hipMalloc synchronise the device,
+        // and a serving process whose batches differ by a few per cent should stop paying that after its first few calls
         size_t want = std::max(bytes, (size_t) 4096);
-        want += want / 4;
+        want += regrow ? want : want / 4;
         HIPCHK(hipMalloc(&p, want));
         cap = want;
         return VSR_OK;
@@ -98,11 +101,12 @@ struct PinBuf {
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return VSR_OK;
+        const bool regrow = p != nullptr;
         if (p) (void) hipHostFree(p);
         p = nullptr;
         cap = 0;
         size_t want = std::max(bytes, (size_t) 4096);
-        want += want / 4;
+        want += regrow ? want : want / 4;                    // (as DevBuf)
         HIPCHK(hipHostMalloc(&p, want, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer(&dp, p, 0));
         cap = want;
