@@ -928,8 +928,11 @@ def main():
         try:
             # setup pass (untimed, before the W warm-up steps; VSR_BENCH_NO_SETUP_PASS=1 skips it): every session searches every
             # batch once.  The driver's W = 5 steps are 2 ms of GPU work behind seconds of host-side setup with the GPU idle;
-            # measured, a 20-step region then runs at 0.38-0.40 ms per step against 0.34 after this pass (sessions' workspaces at
-            # their final size, GPU out of its idle power state) -- the rate of the `sustained` leg and of any serving process.
+            # measured, a 20-step region then runs at 0.39-0.41 ms per step against 0.345 after this pass -- the rate of the
+            # `sustained` leg and of any serving process.  What the pass warms (VSR_BENCH_COLD_EXPERIMENT): not the
+            # batches (48 steps over the warm-up's own five batches do as well), not the streams (200 empty launches each: no
+            # effect), not the shader clock (100 ms of bf16 GEMMs: no effect); ~10 ms of this HBM-bound load itself is what it
+            # takes (a plain 20 ms copy loop closes half of the gap): the memory side's power management ramps on sustained traffic.
             if os.environ.get("VSR_BENCH_NO_SETUP_PASS") != "1" and not state.get("skip_setup_pass"):
                 for _ in range(nb * max(1, state["n_sess"])):
                     step()
@@ -1027,6 +1030,41 @@ def main():
     if world == 1 and os.environ.get("VSR_BENCH_NO_SETUP_PASS") != "1":
         state["skip_setup_pass"] = True
         try:
+            exp = os.environ.get("VSR_BENCH_COLD_EXPERIMENT", "")      # development: what the setup pass actually warms
+            if exp == "gemm":                                          # ... the GPU's clocks? 100 ms of unrelated work
+                ta = torch.randn((8192, 8192), device=dev, dtype=torch.bfloat16)
+                t_end = time.perf_counter() + 0.1
+                while time.perf_counter() < t_end:
+                    (ta @ ta).sum().item()
+                del ta
+            elif exp == "copy":                                        # ... the memory clocks? 20 ms of plain HBM traffic
+                tc = torch.empty((1 << 29,), device=dev, dtype=torch.uint8)
+                td = torch.empty_like(tc)
+                t_end = time.perf_counter() + 0.02
+                while time.perf_counter() < t_end:
+                    td.copy_(tc)
+                    torch.cuda.synchronize()
+                del tc, td
+            elif exp == "noop":                                        # ... or the streams' queues? 200 empty launches per stream
+                for sx in s_scan:
+                    with torch.cuda.stream(sx):
+                        tz = torch.empty((64,), device=dev)
+                        for _ in range(200):
+                            tz.zero_()
+                torch.cuda.synchronize()
+            elif exp == "same1":                                       # ... 8 calls of ONE batch per session
+                for j in range(int(os.environ.get("VSR_BENCH_COLD_CALLS", "8")) * state["n_sess"]):
+                    sess = sessions[j % state["n_sess"]]
+                    corpus.search_device(ptr(d_qs[0]), nq, k, "l2", filt[legs[0]][0], ptr(d_views[0][1]), ptr(d_views[0][2]),
+                                         ptr(d_rows[0]), ptr(d_views[0][3]), ptr(d_cnts[0]), ptr(d_views[0][0]), session=sess)
+                torch.cuda.synchronize()
+            elif exp == "same":                                        # ... or the sessions? 48 steps over the warm-up's own batches
+                for j in range(48):
+                    b = j % max(1, min(nb, args.warmup))
+                    sess = sessions[j % state["n_sess"]]
+                    corpus.search_device(ptr(d_qs[b]), nq, k, "l2", filt[legs[0]][b], ptr(d_views[0][1]), ptr(d_views[0][2]),
+                                         ptr(d_rows[0]), ptr(d_views[0][3]), ptr(d_cnts[0]), ptr(d_views[0][0]), session=sess)
+                torch.cuda.synchronize()
             rc0 = timed_leg(legs[0], args.steps, args.warmup)
             if not rc0["flagged"]:
                 cold = {"value": round(nq * args.steps / rc0["dt"], 1), "unit": "queries/s",
@@ -1134,7 +1172,8 @@ def main():
                    "sharding": f"row-range x{world}", "recall": None, "batches_in_flight": state["n_sess"],
                    "setup_pass": {"steps": state.get("setup_pass_steps", 0),
                                   "note": "untimed, before the warm-up steps: every session searches every distinct batch once "
-                                          "(workspaces sized, GPU out of its idle power state); VSR_BENCH_NO_SETUP_PASS=1 skips it"}},
+                                          "(~17 ms of the step's own HBM-bound load: the memory side's clocks ramp on sustained traffic; "
+                                          "`cold_start` is the same leg without it); VSR_BENCH_NO_SETUP_PASS=1 skips it"}},
         "roofline": main_rec["roofline"],
         "setup_s": {"generate": round(t_gen, 1), "load": round(t_load, 1)},
         # what this rank keeps in HBM for the corpus: the fp32 rows (exact re-rank, K1), the hi-only bf16 screening planes and,
