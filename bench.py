@@ -1194,6 +1194,47 @@ def main():
     if sustained:
         out["sustained"] = sustained
 
+    # ---- sibling record (N = 1): the headline leg's queries in batches four times as large -- what a caller that can wait for
+    # 4000 queries gets (and the shape a rank of a weak-scaling job sees when its queue is deep): more queries share every pass
+    if world == 1 and sim_world <= 1 and nb >= 4 and os.environ.get("VSR_BENCH_NO_LARGE_BATCH") != "1":
+        try:
+            mult = 4
+            nbl = nb // mult
+            lq = [torch.from_numpy(np.ascontiguousarray(allvec[g * mult * nq:(g + 1) * mult * nq])).to(dev) for g in range(nbl)]
+            lf = [corpus.pack_filters([f for b in range(g * mult, (g + 1) * mult) for f in filt[legs[0]][b]._keep]) for g in range(nbl)]
+            nql = mult * nq
+            lo_ = [{"blk": torch.empty((nql, k), dtype=torch.int64, device=dev), "doc": torch.empty((nql, k), dtype=torch.int32, device=dev),
+                    "row": torch.empty((nql, k), dtype=torch.int64, device=dev), "dist": torch.empty((nql, k), dtype=torch.float32, device=dev),
+                    "cnt": torch.empty((nql,), dtype=torch.int32, device=dev)} for _ in range(state["n_sess"])]
+
+            def lstep(i):
+                o, g = lo_[i % state["n_sess"]], i % nbl
+                corpus.search_device(ptr(lq[g]), nql, k, "l2", lf[g], ptr(o["blk"]), ptr(o["doc"]), ptr(o["row"]), ptr(o["dist"]),
+                                     ptr(o["cnt"]), None, session=sessions[i % state["n_sess"]])
+            for i in range(2 * state["n_sess"]):
+                lstep(i)
+            torch.cuda.synchronize()
+            f0 = flagged()
+            lsteps = max(6, args.steps // 2)
+            tl0 = time.perf_counter()
+            for i in range(lsteps):
+                lstep(i)
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - tl0
+            # parity: the first 1000 queries of large batch 0 are the headline leg's batch 0 -- same rows, same distances
+            corpus.search_device(ptr(d_qs[0]), nq, k, "l2", filt[legs[0]][0], ptr(d_views[0][1]), ptr(d_views[0][2]), ptr(d_rows[0]),
+                                 ptr(d_views[0][3]), ptr(d_cnts[0]), ptr(d_views[0][0]))
+            lstep(0)
+            torch.cuda.synchronize()
+            same = bool((lo_[0]["row"][:nq] == d_rows[0]).all().item() and (lo_[0]["dist"][:nq] == d_views[0][3]).all().item())
+            out["large_batch"] = {"queries_per_step": int(nql), "steps": int(lsteps), "ms_per_step": round(dtl / lsteps * 1e3, 4),
+                                  "same_results_as_1000_query_calls": same,
+                                  "value": round(nql * lsteps / dtl, 1), "unit": "queries/s", "flagged": int(flagged() - f0),
+                                  "note": "NOT the headline: the same queries and filters in calls of 4000 (four headline batches "
+                                          "concatenated), three calls in flight"}
+        except Exception as exc:
+            out.setdefault("leg_errors", {})["large_batch"] = repr(exc)
+
     # ---- sibling line (N = 1): the same headline leg with the int8 planes switched off (VSR_NO_INT8): hi-only bf16 planes,
     # 260 bytes per row instead of 132, fp32 accumulation, same exact results ----
     if world == 1 and sim_world <= 1 and not args.no_bf16_line:
