@@ -406,6 +406,31 @@ def test_hnsw_limits_device_api_and_visited_forms(ctx, oracle, monkeypatch):
     monkeypatch.setenv("VSR_HNSW_VISITED", "global")
     check(40, 40)
     monkeypatch.delenv("VSR_HNSW_VISITED")
+    # the predicate-aware walk on this graph: neighbour lists of 80 (two 64-lane steps per list), few rows permitted (the
+    # two-hop expansion runs into its 256-candidate cap), under every form of the visited set
+    import vsrbac
+    allowed = (rng.random(n) < 0.08).astype(np.uint8)
+    flt = corpus.filter_from_bytemask(allowed, vsrbac.BITMAP)
+    gpu.set_predicate_aware(True)
+
+    def check_pa(ef, k):
+        res, vis = gpu.search(q, k, ef, "l2", [flt] * nq)
+        for i in range(nq):
+            rows_o, dist_o, _, nv = oh.search_predicate_aware(q[i], ef, allowed)
+            keep = allowed[rows_o] != 0
+            want, wd = rows_o[keep][:k], dist_o[keep][:k]
+            assert res.counts[i] == want.size, (ef, i, res.counts[i], want.size)
+            np.testing.assert_array_equal(res.rows[i, :want.size], want)
+            np.testing.assert_array_equal(res.dist[i, :want.size], np.sqrt(wd).astype(np.float32))
+            assert vis[i] == nv, (ef, i, vis[i], nv)
+
+    check_pa(40, 40)
+    check_pa(600, 100)
+    for form in ("hash:8192", "hash:256", "global"):
+        monkeypatch.setenv("VSR_HNSW_VISITED", form)
+        check_pa(40, 40)
+    monkeypatch.delenv("VSR_HNSW_VISITED")
+    gpu.set_predicate_aware(False)
     gpu.free()
     corpus.free()
 
