@@ -30,7 +30,15 @@ def build(force=False):
     else:
         # make decides (the libraries depend on the sources): a stale library must never check a newer header's functions;
         # where no compiler is at hand the prebuilt libraries are used as they are
-        rc = subprocess.call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL if have else None)
+        # (one process at a time: the ranks of a multi-GPU bench all come through here at once)
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                rc = subprocess.call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL,
+                                     stderr=subprocess.DEVNULL if have else None)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
         if rc != 0 and not have:
             raise RuntimeError("oracle: make failed and no prebuilt library is present")
     if os.path.isdir("/root/reference"):
