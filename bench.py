@@ -355,11 +355,12 @@ def hnsw_legs(args, torch, ctx, orc, box, qvec, k, dev):
     return cpu, gpu
 
 
-def ivf_leg(args, torch, vsrbac, ctx, orc, x, blk, doc, qvec, k, dev):
+def ivf_leg(args, torch, vsrbac, ctx, orc, x, blk, doc, qvec, k, dev, rows=None, lists=None, probes_list=(1, 4, 10, 32)):
     """The `ivf` leg: CREATE INDEX ... USING ivfflat on the GPU (k-means on the sample, every row into its list), then
-    probes in {1, 4, 10, 32} through vsr_ivf_search_device; beside it pgvector's scan of the same lists on one core."""
-    n3 = min(int(args.ivf_rows), len(x))
-    lists = max(10, n3 // 1000)                                        # pgvector's guidance: rows / 1000 up to 1M rows
+    probes in {1, 4, 10, 32} through vsr_ivf_search_device; beside it pgvector's scan of the same lists on one core.
+    rows / lists / probes_list: another index shape (the reference's own: lists = 100, ivfflat.probes = 5)."""
+    n3 = min(int(rows if rows is not None else args.ivf_rows), len(x))
+    lists = int(lists) if lists is not None else max(10, n3 // 1000)   # pgvector's guidance: rows / 1000 up to 1M rows
     x3 = x[:n3]
     dim = x3.shape[1]
     c3 = ctx.load_corpus(x3, blk[:n3], doc[:n3])
@@ -387,7 +388,7 @@ def ivf_leg(args, torch, vsrbac, ctx, orc, x, blk, doc, qvec, k, dev):
     start = np.concatenate([[0], np.cumsum(np.bincount(row_list, minlength=lists))]).astype(np.int64)
     x_lo = np.ascontiguousarray(x3[order])
     sweep = []
-    for probes in (1, 4, 10, 32):
+    for probes in probes_list:
         if probes > lists:
             break
         call = lambda: gidx.search_device(ptr(d_q), nq, k, probes, "l2", None, ptr(o_blk), ptr(o_doc), ptr(o_row), ptr(o_dist),
@@ -1491,6 +1492,12 @@ def main():
                 out["ivf"] = ivf_leg(args, torch, vsrbac, ctx, orc, x, blk, doc, qvec, k, dev)
             except Exception as exc:
                 out["ivf"] = {"error": repr(exc)}
+            try:      # the reference's own ivfflat parameters on a corpus the size of a large role partition: lists = 100 (pgvector's
+                      # default: initialize_partitions.py:404-409 creates the index without a WITH clause), nprobe = 5 (config_params.json:2)
+                out["ivf_reference_params"] = ivf_leg(args, torch, vsrbac, ctx, orc, x, blk, doc, qvec, k, dev,
+                                                      rows=min(300_000, args.ivf_rows), lists=100, probes_list=(5,))
+            except Exception as exc:
+                out["ivf_reference_params"] = {"error": repr(exc)}
         checks = {leg: spot_check(leg, orc, m) for leg in legs}
         out["parity_spot_check"] = checks[legs[0]]
         for leg in legs[1:]:
