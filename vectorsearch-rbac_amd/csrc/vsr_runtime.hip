@@ -1511,7 +1511,10 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
                 for (ScanGroup& gs : plan.groups_s) gs.partial_begin = 0u;
             }
         }
-        for (uint32_t stride = ctx->sample_stride; !ok && stride >= 2; stride = plan.k2g ? stride / 2 : 0) {
+        // a sample too thin for some query at the configured stride is taken more densely (8, 4, 2) before the plan is given up:
+        // K2g's 256-row tiles on a small corpus, and K2w over many small parts (IVFFlat lists: probes x ~1000 rows per query
+        // used to fall back to the legacy kernels as soon as one query's lists added up to more than its candidate buffer)
+        for (uint32_t stride = ctx->sample_stride; !ok && stride >= 2; stride /= 2) {
             plan.sample_stride = stride;
             const double ss = stride;
             double frac = 1.0 / ss;
