@@ -1511,10 +1511,13 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
                 for (ScanGroup& gs : plan.groups_s) gs.partial_begin = 0u;
             }
         }
-        // a sample too thin for some query at the configured stride is taken more densely (8, 4, 2) before the plan is given up:
+        // A sample too thin for some query at the configured stride is taken more densely (8, 4, 2) before the plan is given up:
         // K2g's 256-row tiles on a small corpus, and K2w over many small parts (IVFFlat lists: probes x ~1000 rows per query
-        // used to fall back to the legacy kernels as soon as one query's lists added up to more than its candidate buffer)
-        for (uint32_t stride = ctx->sample_stride; !ok && stride >= 2; stride /= 2) {
+        // used to fall back to the legacy kernels as soon as one query's lists added up to more than its candidate buffer).
+        // Among the strides that make a valid plan the first one is preferred that also seeds every query with more than a
+        // few thousand rows: a query that fits its buffer may run with an open threshold, but then EVERY one of its rows is a
+        // candidate (IVFFlat, 4 probes of ~1000 rows: 4000 appended keys per query, slower than 10 probes with seeds).
+        auto evaluate = [&](uint32_t stride, bool& soft_thin) -> bool {
             plan.sample_stride = stride;
             const double ss = stride;
             double frac = 1.0 / ss;
@@ -1528,7 +1531,7 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
             const double lambda = (double) plan.keep * frac;
             const uint32_t seed_m = (uint32_t) std::ceil(lambda + 6.0 * std::sqrt(lambda)) + 4;
             plan.kp_frac = (float) lambda;
-            ok = seed_m <= GQ_SAMPLE_CAP / 4;
+            bool good = seed_m <= GQ_SAMPLE_CAP / 4;
             // fine passes: any query whose per-column minima (one per 64 rows of a sampled tile; K2g: one per 128) would be
             // fewer than 4 m: one minimum per lane instead (4 x as many)
             est.assign((size_t) nq, 0.0);
@@ -1551,14 +1554,30 @@ static bool make_plan(const vsr_ctx* ctx, const vsr_corpus* c, int nq, int k, in
                 const double p_entry = std::min(1.0, gdens_s[gi] * rows_per_entry);    // a bitmap may leave an entry without rows
                 for (uint32_t qi = 0; qi < gs.q_count; ++qi) est[plan.q_slots[gs.q_begin + qi]] += sampled * entries_per_tile * p_entry;
             }
+            soft_thin = false;
             for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
                 const vsr_filter* f = fof(q);
                 const int64_t allowed = f ? f->allowed_rows : c->n;
                 // the sample must be thick enough to reach rank m (with a margin where a bitmap makes the count random),
                 // unless all of the query's rows fit its buffer anyway
                 const bool exact_count = !f || f->allowed_rows == f->scanned_rows;
-                if (allowed > (int64_t) GQ_CAP && est[q] < (exact_count ? 1.25 * seed_m + 8.0 : 2.0 * seed_m)) ok = false;
+                const bool thin = est[q] < (exact_count ? 1.25 * seed_m + 8.0 : 2.0 * seed_m);
+                if (allowed > (int64_t) GQ_CAP && thin) good = false;
+                if (allowed > (int64_t) (8 * plan.keep) && allowed > 2048 && thin) soft_thin = true;
             }
+            return good;
+        };
+        uint32_t first_ok = 0, chosen = 0;
+        for (uint32_t stride = ctx->sample_stride; !ok && !chosen && stride >= 2; stride /= 2) {
+            bool soft = false;
+            if (evaluate(stride, soft)) {
+                if (!first_ok) first_ok = stride;
+                if (!soft) chosen = stride;
+            }
+        }
+        if (!ok && (chosen || first_ok)) {
+            bool soft = false;
+            ok = evaluate(chosen ? chosen : first_ok, soft);      // (sets the plan's stride, seed fraction and the groups' flags)
         }
         plan.selq.resize((size_t) nq);
         for (uint32_t q = 0; q < (uint32_t) nq; ++q) {
