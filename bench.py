@@ -951,6 +951,7 @@ def main():
             print(f"[bench] overlapped loop failed in warm-up ({exc!r}); falling back to one batch in flight, serial "
                   f"exchange", file=sys.stderr, flush=True)
             state["overlap"], state["n_sess"], state["open"] = False, 1, 0
+            state["fell_back"] = repr(exc)                    # recorded in the line (config.choreography_fallback), not only on stderr
             torch.cuda.synchronize()
             for _ in range(warmup):
                 step()
@@ -1506,6 +1507,7 @@ def main():
         if not all(c["ids_and_distances_identical"] for c in checks.values()):
             print(json.dumps(out), flush=True)
             raise SystemExit("parity spot check failed: GPU results differ from the oracle")
+    out["config"]["choreography_fallback"] = state.get("fell_back")     # None: the batches-in-flight loop ran as planned
     if parts > 1:
         out["config"]["exchange"] = (f"one all-gather + merge per {G} batches on a second stream, overlapped with the "
                                      f"scans of the next batches" if state["overlap"] else
